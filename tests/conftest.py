@@ -1,0 +1,45 @@
+"""pytest configuration: registers the `gpu` marker and puts the repo root on sys.path."""
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
+                  if not os.path.basename(p).startswith("langevin"))
+
+
+def load_golden(name):
+    """Returns (params dict keyed like the reference state_dict, incl. the '.bias' aliases;
+    dict of the remaining arrays)."""
+    raw = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    params, rest = {}, {}
+    for k in raw.files:
+        if k.startswith("sd/"):
+            params[k[3:]] = torch.from_numpy(raw[k].copy())
+        else:
+            rest[k] = raw[k]
+    for k in list(params):
+        if k.endswith("actnorm.b"):
+            params[k + "ias"] = params[k]
+    return params, rest
+
+
+@pytest.fixture(scope="session")
+def gpu_device():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    return torch.device("cuda:0")

@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own
+``model.py`` (imported read-only from /root/reference, CPU, fp32 + an fp64 tie-breaker).
+
+Runs only in the build container (the reference does not exist on the GPU box); the
+.npz files it writes are committed.  Nothing of the reference's source is stored: the
+files hold inputs (weights, z) and the outputs the reference computed for them.
+
+    python tests/golden/make_golden.py            # rewrites every fixture
+
+Call sites restated here because they live inside a closure of train.py and cannot be
+imported: log-prob assembly (train.py:316-320) and the Langevin update (train.py:311-326).
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import model as ref  # noqa: E402  (the reference's model.py)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(4)
+
+
+def hps_for(width, depth=5, coupling=1):
+    return types.SimpleNamespace(f_n_levels=1, f_depth=depth, f_flow_permutation=2,
+                                 f_width=width, f_flow_coupling=coupling)
+
+
+def build_netF(nz, width, seed, fcz_std, all_std, depth=5):
+    """Reference init under fixed seeds (W init uses numpy QR, model.py:176), then the
+    perturbations SURVEY 8c prescribes so that the coupling is non-trivial."""
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    net = ref._netF(hps_for(width, depth), nz=nz)
+    g = torch.Generator().manual_seed(seed + 1000)
+    with torch.no_grad():
+        for name, prm in net.named_parameters():
+            if ".fc_zeros." in name:
+                prm.add_(torch.randn(prm.shape, generator=g) * fcz_std)
+        if all_std > 0:
+            for name, prm in net.named_parameters():
+                if name.endswith(".bias"):
+                    continue
+                if name.endswith("fc_1.b") or name.endswith("fc_2.b"):
+                    continue
+                prm.add_(torch.randn(prm.shape, generator=g) * all_std)
+    return net
+
+
+def ll_of(z1, logdet):
+    prior_ll = -0.5 * (z1 ** 2)                                     # train.py:317
+    prior_ll = prior_ll.flatten(1).sum(-1) + np.log(2 * np.pi)      # train.py:318
+    return prior_ll + logdet                                        # train.py:319
+
+
+def run_case(name, nz, width, B, sigma_z, seed, fcz_std=0.05, all_std=0.0, with_param_grads=True):
+    net = build_netF(nz, width, seed, fcz_std, all_std)
+    g = torch.Generator().manual_seed(seed + 77)
+    z = (sigma_z * torch.randn(B, nz, generator=g)).float()
+    obj0 = torch.zeros(B)
+
+    out = {"meta_nz": np.int64(nz), "meta_width": np.int64(width), "meta_depth": np.int64(5),
+           "meta_B": np.int64(B), "z": z.numpy().copy()}
+    for k, v in net.state_dict().items():
+        if k.endswith(".bias"):      # alias of '.b' (model.py:231); re-created on load
+            continue
+        out["sd/" + k] = v.detach().numpy().copy()
+
+    # forward + log-prob (train.py:316-319)
+    zz = z.clone().requires_grad_(True)
+    z1, logdet, eps = net(zz, objective=obj0.clone(), init=False)
+    assert eps == []
+    ll = ll_of(z1, logdet)
+    out["z1"] = z1.detach().numpy().copy()
+    out["logdet"] = logdet.detach().numpy().copy()
+    out["ll"] = ll.detach().numpy().copy()
+
+    # d(-sum ll)/dz (train.py:320-323)
+    (gz,) = torch.autograd.grad(-ll.sum(), zz, retain_graph=True)
+    out["grad_z"] = gz.numpy().copy()
+
+    # d(-mean ll)/dtheta (train.py:410-411)
+    if with_param_grads:
+        net.zero_grad()
+        (-ll.mean()).backward()
+        for k, prm in net.named_parameters():
+            if k.endswith(".bias"):
+                continue
+            if prm.grad is None:
+                out["gradnone/" + k] = np.zeros(1, dtype=np.int8)
+            else:
+                out["grad/" + k] = prm.grad.detach().numpy().copy()
+
+    # intermediate per-block outputs (for per-block kernel parity)
+    with torch.no_grad():
+        zi, li = z.clone(), obj0.clone()
+        steps = net.revnet2d_s[0].revnet2d_step_s
+        zs, ls = [], []
+        for i in range(len(steps)):
+            zi, li = steps[i](zi, li, False, False)
+            zs.append(zi.numpy().copy())
+            ls.append(li.numpy().copy())
+        out["block_z"] = np.stack(zs)
+        out["block_logdet"] = np.stack(ls)
+
+    # fp64 tie-breaker: the same module in double
+    net64 = build_netF(nz, width, seed, fcz_std, all_std).double()
+    with torch.no_grad():
+        z1d, ldd, _ = net64(z.double(), objective=torch.zeros(B, dtype=torch.float64))
+        out["ll_f64"] = ll_of(z1d, ldd).numpy().copy()
+        out["z1_f64"] = z1d.numpy().copy()
+
+    # reverse path (model.py:484-498): sample from the prior, and round-trip of z1
+    with torch.no_grad():
+        eps_in = torch.randn(B, nz, generator=g).float()
+        out["rev_in"] = eps_in.numpy().copy()
+        xr, nobj = net(eps_in.clone(), objective=torch.zeros(B), reverse=True, return_obj=True)
+        out["rev_out"] = xr.numpy().copy()
+        out["rev_negobj"] = nobj.numpy().copy()
+        rt = net(z1.detach().clone(), objective=torch.zeros(B), reverse=True)
+        out["roundtrip"] = rt.numpy().copy()
+
+    path = os.path.join(HERE, name + ".npz")
+    np.savez(path, **out)
+    print(f"{name}: nz={nz} w={width} B={B} ll[mean]={ll.mean().item():.4f} "
+          f"max|z1|={z1.abs().max().item():.3f} rt_err={(rt - z).abs().max().item():.2e} "
+          f"f32-vs-f64 rel={(np.abs(out['ll'].astype(np.float64) - out['ll_f64']) / np.abs(out['ll_f64'])).max():.2e} "
+          f"-> {os.path.getsize(path) / 1e6:.2f} MB")
+
+
+def run_langevin(name, nz=100, width=64, B=16, K=3, ngf=8, seed=5):
+    """Noise-free K-step Langevin trajectory (train.py:311-326 with g_l_with_noise off, as in
+    train.py:624-625) using the reference's _netG (svhn variant) and _netF.  The generator's
+    z-gradient at every step is stored, so the build's harness is pinned without needing
+    a generator of its own."""
+    net = build_netF(nz, width, seed, 0.05, 0.0)
+    torch.manual_seed(seed)
+    gargs = types.SimpleNamespace(dataset="svhn", nz=nz, ngf=ngf, nc=3, g_activation="lrelu",
+                                  g_activation_leak=0.2, g_batchnorm=False)
+    netG = ref._netG(gargs)
+    netG.apply(ref.weights_init_xavier)
+    g = torch.Generator().manual_seed(seed + 9)
+    x = torch.tanh(torch.randn(B, 3, 32, 32, generator=g))
+    z0 = torch.randn(B, nz, 1, 1, generator=g)
+    sigma, s = 0.3, 0.1
+    mse = torch.nn.MSELoss(reduction="sum")
+
+    z = z0.clone().detach()
+    z.requires_grad = True
+    traj, gg_l, gf_l, f_l = [], [], [], []
+    for _ in range(K):
+        x_hat = netG(z)
+        g_log_lkhd = 1.0 / (2.0 * sigma * sigma) * mse(x_hat, x)
+        z_grad_g = torch.autograd.grad(g_log_lkhd, z)[0]
+        z1, logdet, _ = net(torch.squeeze(z), objective=torch.zeros(int(z.shape[0])), init=False)
+        ll = ll_of(z1, logdet)
+        f_log_lkhd = -ll.sum()
+        z_grad_f = torch.autograd.grad(f_log_lkhd, z)[0]
+        z.data = z.data - 0.5 * s * s * (z_grad_g + z_grad_f)
+        traj.append(z.data.view(B, nz).numpy().copy())
+        gg_l.append(z_grad_g.view(B, nz).numpy().copy())
+        gf_l.append(z_grad_f.view(B, nz).numpy().copy())
+        f_l.append(f_log_lkhd.item())
+    out = {"meta_nz": np.int64(nz), "meta_width": np.int64(width), "meta_depth": np.int64(5),
+           "meta_B": np.int64(B), "step_size": np.float64(s),
+           "z0": z0.view(B, nz).numpy().copy(), "traj": np.stack(traj),
+           "grad_g": np.stack(gg_l), "grad_f": np.stack(gf_l), "f_log_lkhd": np.array(f_l)}
+    for k, v in net.state_dict().items():
+        if not k.endswith(".bias"):
+            out["sd/" + k] = v.detach().numpy().copy()
+    path = os.path.join(HERE, name + ".npz")
+    np.savez(path, **out)
+    print(f"{name}: K={K} f_log_lkhd={f_l} -> {os.path.getsize(path) / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    # tiny (all kernels' padding paths), odd B
+    run_case("tiny_nz8_w4_B7", 8, 4, 7, 1.0, seed=11)
+    run_case("tiny_nz8_w4_B37_trained", 8, 4, 37, 1.0, seed=12, fcz_std=0.1, all_std=0.1)
+    # C1 (BASELINE.json configs[0]): SVHN nz=100 w=64 B=256
+    run_case("c1_nz100_w64_B256", 100, 64, 256, 1.0, seed=1)
+    # C3 (headline geometry) at ragged batch sizes, two weight regimes, sigma_z 1 and 3
+    run_case("c3_nz128_w64_B200", 128, 64, 200, 1.0, seed=1)
+    run_case("c3_nz128_w64_B7_trained_s3", 128, 64, 7, 3.0, seed=2, fcz_std=0.1, all_std=0.05,
+             with_param_grads=False)
+    # C5 geometry (CelebA-HQ): nz=100 w=128
+    run_case("c5_nz100_w128_B100", 100, 128, 100, 1.0, seed=3)
+    # caller harness: noise-free Langevin trajectory
+    run_langevin("langevin_nz100_w64_B16_K3")
