@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Headline benchmark: latent-samples/sec through flow + log-det (+ log-prob), CIFAR-10 flow
+geometry nz=128 f_width=64 f_depth=5, B=65536 rows PER GPU of synthetic z (BASELINE.json configs[2]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path over one batch: the fused forward launch (z -> z1, logdet, ll),
+the on-device sum of ll (train.py:320) and -- for N > 1 -- the single RCCL all-reduce of that sum.
+z, the prepared weights and all outputs are resident in HBM when the timed region starts.
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  "roofline":     the forward kernel's algorithmic FLOP/s (HIP-event timed, kernel-only loop) against
+                  the dense fp32 MFMA peak of MI355X,
+  "cpu_baseline": the oracle (PyTorch-CPU restatement of the reference) timed on this box's host
+                  cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+NZ, WIDTH, DEPTH = 128, 64, 5
+B_PER_GPU = 65536
+FLOP_PER_SAMPLE = DEPTH * (2 * NZ * NZ + 2 * (NZ // 2 * WIDTH + WIDTH * WIDTH + WIDTH * NZ))  # 327 680
+BYTES_PER_SAMPLE_FUSED = 8 * NZ + 8                                                            # 1 032 (whole stack fused)
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_weights(seed=1):
+    """Reference-style init (orthogonal W, 0.05 N(0,1) elsewhere) + 0.05 N(0,1) on fc_zeros, built
+    with torch/numpy RNG only (no oracle import on the product path)."""
+    import numpy as np
+    g = torch.Generator().manual_seed(seed)
+    rs = np.random.RandomState(seed)
+    half = NZ // 2
+    out = []
+    for _ in range(DEPTH):
+        rn = lambda *s: torch.randn(*s, generator=g) * 0.05  # noqa: E731
+        q = torch.tensor(np.linalg.qr(rs.randn(NZ, NZ))[0], dtype=torch.float32)
+        out += [rn(NZ), rn(NZ), q, rn(half, WIDTH), rn(WIDTH), rn(WIDTH), rn(WIDTH, WIDTH), rn(WIDTH), rn(WIDTH),
+                rn(WIDTH, NZ), rn(NZ), rn(NZ)]
+    return out
+
+
+def cpu_baseline(weights, budget_s=12.0):
+    """Oracle timed on the host cores: bounded sample = full-size (65536-row) forward+log-prob calls
+    repeated for ~budget_s seconds after 2 warm-ups."""
+    from oracle import flow_oracle as O
+    import lsnf_amd
+    keys = lsnf_amd.flow.BLOCK_PARAM_KEYS
+    p = {}
+    for i in range(DEPTH):
+        for j, k in enumerate(keys):
+            t = weights[i * 12 + j]
+            p[O.block_prefix(i) + k] = t.reshape(1, -1) if t.dim() == 1 else t
+    z = torch.randn(B_PER_GPU, NZ, generator=torch.Generator().manual_seed(1234))
+    threads = torch.get_num_threads()
+    with torch.no_grad():
+        for _ in range(2):
+            O.flow_log_prob(p, z)
+        times = []
+        t_end = time.perf_counter() + budget_s
+        while time.perf_counter() < t_end or len(times) < 3:
+            t0 = time.perf_counter()
+            O.flow_log_prob(p, z)
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": B_PER_GPU / med, "unit": "latent-samples/s", "cores": threads, "kind": "port",
+            "sample": f"{len(times)} full-size calls (B={B_PER_GPU}, nz={NZ}) of oracle.flow_log_prob, "
+                      f"torch-CPU fp32 no_grad, median {med * 1e3:.1f} ms"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the flow path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)   # RCCL
+
+    import lsnf_amd
+    weights = synth_weights(1)
+    plan = lsnf_amd.prepare([w.to(dev) for w in weights], NZ, WIDTH, DEPTH)
+    z = torch.randn(B_PER_GPU, NZ, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
+    z1 = torch.empty_like(z)
+    logdet = torch.empty(B_PER_GPU, device=dev)
+    ll = torch.empty(B_PER_GPU, device=dev)
+    total = torch.zeros(1, device=dev)
+
+    def step():
+        lsnf_amd.forward(plan, z, out=(z1, logdet, ll))
+        torch.sum(ll, dim=0, keepdim=True, out=total)
+        if dist is not None:
+            dist.all_reduce(total)      # the single collective of the path: sum of log-prob over ranks
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    # kernel-only loop for the roofline: HIP events on the launch stream around K back-to-back launches
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(5):
+        lsnf_amd.forward(plan, z, out=(z1, logdet, ll))
+    torch.cuda.synchronize()
+    kl = max(20, min(args.steps, 200))
+    e0.record()
+    for _ in range(kl):
+        lsnf_amd.forward(plan, z, out=(z1, logdet, ll))
+    e1.record()
+    torch.cuda.synchronize()
+    kern_ms = e0.elapsed_time(e1) / kl
+    # prepare (weight folding + fp64 Gauss-Jordan), amortised over the Langevin loop in production
+    p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    wd = [w.to(dev) for w in weights]
+    p0.record()
+    for _ in range(5):
+        lsnf_amd.prepare(wd, NZ, WIDTH, DEPTH, plan=plan)
+    p1.record()
+    torch.cuda.synchronize()
+    prep_ms = p0.elapsed_time(p1) / 5
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * B_PER_GPU * args.steps / elapsed
+        tflops = FLOP_PER_SAMPLE * B_PER_GPU / (kern_ms * 1e-3) / 1e12
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "latent-samples/sec through flow+logdet, nz=128 B=65536",
+            "value": value, "unit": "latent-samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "CIFAR-10 flow prior nz=128 f_width=64 f_depth=5 affine, forward+logdet+log-prob, "
+                                   "B=65536 synthetic z per GPU (BASELINE.json configs[2])",
+                       "rows_per_gpu": B_PER_GPU, "global_rows": world * B_PER_GPU,
+                       "parallelism": f"dp{world} (rows sharded, one all-reduce of sum ll)" if world > 1 else "single GPU",
+                       "prepare_ms_not_in_step": prep_ms},
+            "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                         "kernel": "lsnf_fwd_kernel<FwdCfg<2,2>>", "kernel_ms": kern_ms,
+                         "flop_per_launch": FLOP_PER_SAMPLE * B_PER_GPU,
+                         "hbm_frac_secondary": BYTES_PER_SAMPLE_FUSED * B_PER_GPU / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(weights)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

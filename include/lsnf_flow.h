@@ -1,0 +1,121 @@
+/*
+ * lsnf_flow.h -- C ABI of the MI355X (gfx950) latent-flow-prior library `liblsnf_flow.so`.
+ *
+ * The reference (jianwen-xie/Latent-Space-Normalizing-Flow) has no native/FFI layer: its
+ * replaceable unit is the Python class `_netF` (reference model.py:460-498).  This header is
+ * the boundary a maintainer binds from Python (ctypes) to make `_netF`
+ * run on hand-written HIP kernels.  Every entry point names the reference code it replaces.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only, no torch / STL types.
+ *   - every `const float*` / `float*` below is a DEVICE pointer (HBM) unless the name ends
+ *     in `_host`; tensors are dense row-major fp32: z is (B, nz), per-sample vectors are (B,).
+ *   - `stream` is a `hipStream_t` passed as `void*` (NULL = the null stream).  Calls are
+ *     asynchronous, do not synchronise the device and keep no global mutable state, so they
+ *     are re-entrant per stream and hipGraph-capturable (no allocation inside).
+ *   - return value: 0 on success, a negative LSNF_E_* code on failure; `lsnf_last_error()`
+ *     returns a thread-local message.  Nothing falls back to a CPU path.
+ *
+ * Geometry: nz even, 2 <= nz <= 128; 1 <= width <= 128; 1 <= depth <= 16;
+ * coupling 1 (affine, reference default train.py:63) or 0 (additive, model.py:407-408).
+ */
+#ifndef LSNF_FLOW_H
+#define LSNF_FLOW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSNF_ABI_VERSION 1
+
+#define LSNF_OK 0
+#define LSNF_E_ARG (-1)       /* bad argument (NULL pointer, size out of range, misaligned) */
+#define LSNF_E_GEOMETRY (-2)  /* nz / width / depth outside what the kernels are built for */
+#define LSNF_E_HIP (-3)       /* a HIP runtime call or kernel launch failed */
+#define LSNF_E_NODEVICE (-4)  /* no gfx950 device visible */
+
+/* Number of live parameter tensors per coupling block, in this order (names as in the
+ * reference's state_dict, prefix `revnet2d_s.0.revnet2d_step_s.{i}.`; shapes row-major):
+ *   0 actnorm.b            (nz)         model.py:230
+ *   1 actnorm.logs         (nz)         model.py:233
+ *   2 invertible_1x1_conv.w(nz, nz)     model.py:177
+ *   3 f.fc_1.w             (nz/2, w)    model.py:318
+ *   4 f.fc_1.actnorm.b     (w)
+ *   5 f.fc_1.actnorm.logs  (w)
+ *   6 f.fc_2.w             (w, w)
+ *   7 f.fc_2.actnorm.b     (w)
+ *   8 f.fc_2.actnorm.logs  (w)
+ *   9 f.fc_zeros.w         (w, n_out)   model.py:340   n_out = nz (affine) | nz/2 (additive)
+ *  10 f.fc_zeros.b         (n_out)      model.py:341
+ *  11 f.fc_zeros.logs      (n_out)      model.py:342
+ * (`f.fc_1.b`, `f.fc_2.b` are dead parameters in the reference, model.py:319,327-330, and the
+ * `.bias` keys alias `.b`, model.py:231: none of them cross this boundary.) */
+#define LSNF_PARAMS_PER_BLOCK 12
+
+int lsnf_abi_version(void);
+const char* lsnf_last_error(void);
+
+/* Device query: writes the gfx arch name (e.g. "gfx950") of device `device`; LSNF_E_NODEVICE
+ * if there is none.  Only call that touches the device without doing work. */
+int lsnf_device_arch(int device, char* buf, size_t buflen);
+
+/* ---- prepared weights ("plan") ---------------------------------------------------------
+ * Batch-independent work of one `_netF` evaluation, hoisted out of the per-call path:
+ * exp(3*logs) folding of the three actnorms (model.py:264-268), de-interleave of fc_zeros'
+ * shift / scale columns (model.py:411-413), log|det W| in float64 (model.py:182), W^-1
+ * (model.py:193), all re-laid-out in MFMA-fragment order.  Valid until a parameter changes. */
+
+/* Size in floats of the prepared-weight buffer for this geometry (0 on bad geometry). */
+size_t lsnf_plan_floats(int nz, int width, int depth, int coupling);
+
+/* Size in bytes of the scratch `lsnf_prepare` needs (float64 LU workspace). */
+size_t lsnf_prepare_scratch_bytes(int nz, int width, int depth);
+
+/* params_host: HOST array of depth*LSNF_PARAMS_PER_BLOCK DEVICE pointers (order above).
+ * plan: device buffer of lsnf_plan_floats() floats, 16-byte aligned.  scratch: device. */
+int lsnf_prepare(const float* const* params_host, int nz, int width, int depth, int coupling,
+                 float* plan, void* scratch, void* stream);
+
+/* ---- forward: replaces `_netF.forward(z, objective)` (model.py:473-483) -----------------
+ * Runs blocks [first_block, first_block+n_blocks) of the stack (model.py:357-360; one block =
+ * revnet2d_step.forward model.py:391-422) on B rows in ONE launch.
+ *   z_in      (B, nz)   input latents
+ *   objective (B) or NULL (= zeros)      running log-det in
+ *   z_out     (B, nz)   output of the last block run
+ *   logdet_out(B)       objective + sum of the blocks' log|det J|
+ *   ll_out    (B) or NULL: -0.5*sum_j z_out^2 + log(2*pi) + logdet_out  (train.py:317-319)
+ *   z_saved   NULL, or ((n_blocks-1), B, nz): outputs of all but the last block, kept for
+ *             lsnf_backward_z / lsnf_backward_params.                                     */
+int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling,
+                 int first_block, int n_blocks, int B,
+                 const float* z_in, const float* objective,
+                 float* z_out, float* logdet_out, float* ll_out, float* z_saved,
+                 void* stream);
+
+/* ---- reverse: replaces `_netF.forward(z, objective, reverse=True)` (model.py:484-498,
+ * block inverse model.py:424-456).  Functional: inputs are not modified (the reference
+ * mutates them in place, model.py:436-438).  objective_out = objective - sum log|det J|
+ * (the reference returns its negation when return_obj=True, model.py:498). */
+int lsnf_reverse(const float* plan, int nz, int width, int depth, int coupling, int B,
+                 const float* z_in, const float* objective,
+                 float* z_out, float* objective_out, void* stream);
+
+/* ---- backward w.r.t. z: replaces autograd of train.py:316-323 ---------------------------
+ * Given upstream gradients g_z1 = dL/dz_out (B,nz) (NULL = 0), g_logdet = dL/dlogdet_out
+ * (B) (NULL = 0) computes g_z_in = dL/dz_in (B,nz).  z_out / z_saved are what lsnf_forward
+ * wrote for the same inputs (full stack: first_block = 0, n_blocks = depth).
+ * If ll_mode != 0 the upstream gradient is that of L = ll_scale * sum_b ll_b, i.e.
+ * g_z1 = -ll_scale*z_out, g_logdet = ll_scale, and the two pointers are ignored
+ * (train.py:320 uses L = -sum ll -> ll_scale = -1). */
+int lsnf_backward_z(const float* plan, int nz, int width, int depth, int coupling, int B,
+                    const float* z_out, const float* z_saved,
+                    const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
+                    float* g_z_in, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSNF_FLOW_H */

@@ -1,0 +1,150 @@
+// lsnf_api.hip -- the C ABI of liblsnf_flow.so (declared in include/lsnf_flow.h).
+// Argument validation happens here, on the host, BEFORE any kernel is launched: operand shapes
+// and alignments are checked against what the kernels and their grids assume.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/lsnf_flow.h"
+#include "lsnf_layout.h"
+
+// kernel launchers (other translation units)
+hipError_t lsnf_launch_prepare(const LsnfGeo& g, const float* const* params_host, float* plan, void* scratch, hipStream_t stream);
+size_t lsnf_prep_scratch_bytes(int nz, int depth);
+hipError_t lsnf_launch_forward(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
+                               const float* z_in, const float* objective, float* z_out, float* logdet_out,
+                               float* ll_out, float* z_saved, int vec4, hipStream_t stream);
+hipError_t lsnf_launch_reverse(const LsnfGeo& g, const float* plan, int B, const float* z_in, const float* objective,
+                               float* z_out, float* objective_out, int vec4, hipStream_t stream);
+hipError_t lsnf_launch_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
+                                  const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
+                                  float* g_z_in, int vec4, hipStream_t stream);
+
+namespace {
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+    return fail(LSNF_E_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
+
+int geo_or_fail(LsnfGeo* g, int nz, int width, int depth, int coupling) {
+    if (lsnf_geo_init(g, nz, width, depth, coupling))
+        return fail(LSNF_E_GEOMETRY, "unsupported geometry nz=%d width=%d depth=%d coupling=%d "
+                    "(need nz even in [2,128], width in [1,128], depth in [1,%d], coupling 1)",
+                    nz, width, depth, coupling, LSNF_MAX_DEPTH);
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int lsnf_abi_version(void) { return LSNF_ABI_VERSION; }
+const char* lsnf_last_error(void) { return g_err; }
+
+int lsnf_device_arch(int device, char* buf, size_t buflen) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
+        return fail(LSNF_E_NODEVICE, "no HIP device %d (count %d)", device, n);
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDeviceProperties");
+    if (buf && buflen) { strncpy(buf, prop.gcnArchName, buflen - 1); buf[buflen - 1] = 0; }
+    return LSNF_OK;
+}
+
+size_t lsnf_plan_floats(int nz, int width, int depth, int coupling) {
+    LsnfGeo g;
+    if (lsnf_geo_init(&g, nz, width, depth, coupling)) return 0;
+    return g.total_floats;
+}
+
+size_t lsnf_prepare_scratch_bytes(int nz, int width, int depth) {
+    (void)width;
+    if (nz < 2 || nz > 128 || depth < 1 || depth > LSNF_MAX_DEPTH) return 0;
+    return lsnf_prep_scratch_bytes(nz, depth);
+}
+
+int lsnf_prepare(const float* const* params_host, int nz, int width, int depth, int coupling, float* plan,
+                 void* scratch, void* stream) {
+    LsnfGeo g;
+    if (int rc = geo_or_fail(&g, nz, width, depth, coupling)) return rc;
+    if (!params_host || !plan || !scratch) return fail(LSNF_E_ARG, "lsnf_prepare: NULL argument");
+    if (!aligned16(plan) || !aligned16(scratch)) return fail(LSNF_E_ARG, "lsnf_prepare: plan/scratch must be 16-byte aligned");
+    for (int i = 0; i < depth * LSNF_PARAMS_PER_BLOCK; ++i)
+        if (!params_host[i] || !aligned4(params_host[i]))
+            return fail(LSNF_E_ARG, "lsnf_prepare: parameter pointer %d (block %d, slot %d) is NULL or misaligned", i,
+                        i / LSNF_PARAMS_PER_BLOCK, i % LSNF_PARAMS_PER_BLOCK);
+    hipError_t e = lsnf_launch_prepare(g, params_host, plan, scratch, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "lsnf_prepare launch");
+    return LSNF_OK;
+}
+
+int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, int first_block, int n_blocks, int B,
+                 const float* z_in, const float* objective, float* z_out, float* logdet_out, float* ll_out,
+                 float* z_saved, void* stream) {
+    LsnfGeo g;
+    if (int rc = geo_or_fail(&g, nz, width, depth, coupling)) return rc;
+    if (B < 0 || B > (1 << 28)) return fail(LSNF_E_ARG, "lsnf_forward: B=%d out of range", B);
+    if (B == 0) return LSNF_OK;   // empty batch: nothing to do (pointers of empty tensors may be NULL)
+    if (!plan || !z_in || !z_out || !logdet_out) return fail(LSNF_E_ARG, "lsnf_forward: NULL argument");
+    if (first_block < 0 || n_blocks < 1 || first_block + n_blocks > depth)
+        return fail(LSNF_E_ARG, "lsnf_forward: blocks [%d,%d) outside [0,%d)", first_block, first_block + n_blocks, depth);
+    if (!aligned16(plan)) return fail(LSNF_E_ARG, "lsnf_forward: plan must be 16-byte aligned");
+    if (!aligned4(z_in) || !aligned4(z_out) || !aligned4(logdet_out) || !aligned4(objective) || !aligned4(ll_out) || !aligned4(z_saved))
+        return fail(LSNF_E_ARG, "lsnf_forward: tensors must be 4-byte aligned");
+    if (B == 0) return LSNF_OK;
+    const int vec4 = (g.half % 4 == 0) && aligned16(z_in) && aligned16(z_out) && (z_saved == nullptr || aligned16(z_saved));
+    hipError_t e = lsnf_launch_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
+                                       z_saved, vec4, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "lsnf_forward launch");
+    return LSNF_OK;
+}
+
+int lsnf_reverse(const float* plan, int nz, int width, int depth, int coupling, int B, const float* z_in,
+                 const float* objective, float* z_out, float* objective_out, void* stream) {
+    LsnfGeo g;
+    if (int rc = geo_or_fail(&g, nz, width, depth, coupling)) return rc;
+    if (B < 0 || B > (1 << 28)) return fail(LSNF_E_ARG, "lsnf_reverse: B=%d out of range", B);
+    if (B == 0) return LSNF_OK;
+    if (!plan || !z_in || !z_out) return fail(LSNF_E_ARG, "lsnf_reverse: NULL argument");
+    if (!aligned16(plan)) return fail(LSNF_E_ARG, "lsnf_reverse: plan must be 16-byte aligned");
+    if (!aligned4(z_in) || !aligned4(z_out) || !aligned4(objective) || !aligned4(objective_out))
+        return fail(LSNF_E_ARG, "lsnf_reverse: tensors must be 4-byte aligned");
+    if (B == 0) return LSNF_OK;
+    const int vec4 = (g.half % 4 == 0) && aligned16(z_in) && aligned16(z_out);
+    hipError_t e = lsnf_launch_reverse(g, plan, B, z_in, objective, z_out, objective_out, vec4, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "lsnf_reverse launch");
+    return LSNF_OK;
+}
+
+int lsnf_backward_z(const float* plan, int nz, int width, int depth, int coupling, int B, const float* z_out,
+                    const float* z_saved, const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
+                    float* g_z_in, void* stream) {
+    LsnfGeo g;
+    if (int rc = geo_or_fail(&g, nz, width, depth, coupling)) return rc;
+    if (B < 0 || B > (1 << 28)) return fail(LSNF_E_ARG, "lsnf_backward_z: B=%d out of range", B);
+    if (B == 0) return LSNF_OK;
+    if (!plan || !z_out || !g_z_in || (depth > 1 && !z_saved)) return fail(LSNF_E_ARG, "lsnf_backward_z: NULL argument");
+    if (!aligned16(plan)) return fail(LSNF_E_ARG, "lsnf_backward_z: plan must be 16-byte aligned");
+    if (!aligned4(z_out) || !aligned4(z_saved) || !aligned4(g_z1) || !aligned4(g_logdet) || !aligned4(g_z_in))
+        return fail(LSNF_E_ARG, "lsnf_backward_z: tensors must be 4-byte aligned");
+    if (B == 0) return LSNF_OK;
+    const int vec4 = (g.half % 4 == 0) && aligned16(z_out) && aligned16(g_z_in) && (z_saved == nullptr || aligned16(z_saved)) &&
+                     (g_z1 == nullptr || aligned16(g_z1));
+    hipError_t e = lsnf_launch_backward_z(g, plan, B, z_out, z_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, vec4,
+                                          (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "lsnf_backward_z launch");
+    return LSNF_OK;
+}
+
+}  // extern "C"

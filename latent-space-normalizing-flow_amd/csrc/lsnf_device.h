@@ -1,0 +1,154 @@
+// lsnf_device.h -- device-side building blocks shared by the forward / reverse / backward kernels.
+// gfx950 (CDNA4) only: wave64, v_mfma_f32_32x32x2_f32, LDS-DMA (global_load_lds_dwordx4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "lsnf_layout.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LSNF_WG_THREADS 256          // 4 waves, one per SIMD; 2 workgroups co-resident per CU
+#define LSNF_WG_WAVES 4
+#define LSNF_WG_SAMPLES (LSNF_WG_WAVES * 32)
+
+#define LSNF_AS1 __attribute__((address_space(1)))
+#define LSNF_AS3 __attribute__((address_space(3)))
+
+// feature offset inside a 32-tile of accumulator register r on lane-half h
+__device__ __forceinline__ constexpr int lsnf_feat(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---- LDS-DMA of one weight panel (KT KiB*4) by the 4 waves of the workgroup -------------------
+// Each wave-instruction moves 1 KiB (64 lanes x 16 B), destination = wave-uniform base + lane*16.
+template <int KT>
+__device__ __forceinline__ void lsnf_issue_panel(const float* __restrict__ gsrc, float* lbuf, int wave, int lane) {
+#pragma unroll
+    for (int s = 0; s < KT; ++s) {
+        const int seg = s * LSNF_WG_WAVES + wave;  // 1 KiB segment index
+        const float* g = gsrc + seg * 256 + lane * 4;
+        float* l = lbuf + seg * 256;
+        __builtin_amdgcn_global_load_lds((const LSNF_AS1 void*)g, (LSNF_AS3 void*)l, 16, 0, 0);
+    }
+}
+
+// Wait for this wave's outstanding LDS-DMA (and any other VMEM), then workgroup barrier:
+// after it every wave's part of the awaited panel is visible and every wave has finished
+// reading the panel that was consumed before.
+__device__ __forceinline__ void lsnf_panel_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// ---- one panel of MFMAs: acc(32 features x 32 samples) += W_panel^T * in ----------------------
+// lbuf: panel in LDS (fragment order), in[kt]: activations tile kt (B operand), acc: C/D.
+template <int KT>
+__device__ __forceinline__ void lsnf_panel_mma(f32x16& acc, const f32x16* in, const float* lbuf, int lane) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(lbuf + ((kt * 4 + g) * 64 + lane) * 4);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], in[kt][4 * g + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], in[kt][4 * g + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], in[kt][4 * g + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], in[kt][4 * g + 3], acc, 0, 0, 0);
+        }
+    }
+}
+
+// accumulator initialised with the per-feature bias (bias block: [h][r], 32 floats per n-tile)
+__device__ __forceinline__ f32x16 lsnf_bias_init(const float* cst, int h) {
+    const f32x4* b = reinterpret_cast<const f32x4*>(cst + h * 16);
+    f32x16 a;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = b[q];
+        a[4 * q + 0] = v[0]; a[4 * q + 1] = v[1]; a[4 * q + 2] = v[2]; a[4 * q + 3] = v[3];
+    }
+    return a;
+}
+
+__device__ __forceinline__ f32x16 lsnf_zero16() {
+    f32x16 a;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+    return a;
+}
+
+__device__ __forceinline__ f32x16 lsnf_relu16(f32x16 a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.0f);
+    return a;
+}
+
+// sigma = sigmoid(p), lsig = log(sigmoid(p)), both stable for any finite p.
+//   reference: scale = sigmoid(h[:,1::2] + 2) (model.py:413; the +2 is folded into the bias),
+//              log(scale) (model.py:418)
+__device__ __forceinline__ void lsnf_sigmoid_logsig(float p, float& sig, float& lsig) {
+    const float a = fabsf(p);
+#ifdef LSNF_FAST_MATH
+    const float e = __expf(-a);
+    const float d = 1.0f + e;
+    const float r = __fdividef(1.0f, d);
+    const float dm1 = d - 1.0f;
+    const float l = (dm1 == 0.0f) ? e : __logf(d) * __fdividef(e, dm1);   // log1p(e)
+#else
+    const float e = expf(-a);           // in (0, 1]
+    const float r = 1.0f / (1.0f + e);
+    const float l = log1pf(e);
+#endif
+    sig = (p >= 0.0f) ? r : e * r;
+    lsig = fminf(p, 0.0f) - l;
+}
+
+// sum of a value held by lanes l and l+32 (the two feature half-groups of one sample)
+__device__ __forceinline__ float lsnf_pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+
+// ---- latent rows <-> split-pad register tiles -------------------------------------------------
+// row: sample index (already clamped to [0,B)), x[t][r] <- feature nat(32*t + o(r,h)).
+template <int HT>
+__device__ __forceinline__ void lsnf_load_rows(f32x16* x, const float* __restrict__ z, long row, int nz, int half,
+                                               int h, bool vec4) {
+    const float* zr = z + row * (long)nz;
+#pragma unroll
+    for (int t = 0; t < 2 * HT; ++t) {
+        const int hh = t / HT, tt = t % HT;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f0 = 32 * tt + 8 * g + 4 * h;
+            const int col0 = hh * half + f0;
+            if (vec4) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (f0 < half) v = *reinterpret_cast<const f32x4*>(zr + col0);
+                x[t][4 * g + 0] = v[0]; x[t][4 * g + 1] = v[1]; x[t][4 * g + 2] = v[2]; x[t][4 * g + 3] = v[3];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[t][4 * g + j] = (f0 + j < half) ? zr[col0 + j] : 0.0f;
+            }
+        }
+    }
+}
+
+template <int HT>
+__device__ __forceinline__ void lsnf_store_rows(const f32x16* x, float* __restrict__ z, long row, int nz, int half,
+                                                int h, bool vec4) {
+    float* zr = z + row * (long)nz;
+#pragma unroll
+    for (int t = 0; t < 2 * HT; ++t) {
+        const int hh = t / HT, tt = t % HT;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f0 = 32 * tt + 8 * g + 4 * h;
+            const int col0 = hh * half + f0;
+            if (vec4) {
+                if (f0 < half) {
+                    f32x4 v = {x[t][4 * g + 0], x[t][4 * g + 1], x[t][4 * g + 2], x[t][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(zr + col0) = v;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (f0 + j < half) zr[col0 + j] = x[t][4 * g + j];
+            }
+        }
+    }
+}

@@ -1,0 +1,96 @@
+// lsnf_layout.h -- geometry and prepared-weight ("plan") layout shared by host and device code.
+//
+// Register/lane convention used by every kernel ("sample-on-lane"):
+//   a wave owns 32 samples; lane l = (m = l & 31 -> sample, h = l >> 5 -> feature half-group).
+//   A 32-feature tile of activations lives in 16 VGPRs per lane: register r of lane (m,h) holds
+//   feature  o(r,h) = (r & 3) + 8*(r >> 2) + 4*h  of sample m.  This is exactly the C/D layout
+//   of v_mfma_f32_32x32x2_f32 (row = feature, col = sample), and -- because the k index of the
+//   MFMA's B operand is (lane >> 5) -- also exactly the B-operand layout of the next GEMM when
+//   register r is used as k-step r.  So activations flow GEMM -> GEMM without leaving VGPRs.
+//
+// "Split-pad" feature coordinates of a latent row (nz features, half = nz/2):
+//   tiles 0..HT-1 hold the first half (features 0..half-1, zero padded to 32*HT),
+//   tiles HT..2HT-1 hold the second half.   c -> natural column: nat(c).
+//
+// A weight "panel" = the 32 output features of one n-tile for all KT k-tiles of a GEMM stage,
+// stored in fragment order so that one ds_read_b128 per lane feeds 4 MFMAs:
+//   panel[((kt*4 + g)*64 + lane)*4 + j] = M[k = 32*kt + 8*g + 4*(lane>>5) + j][n = 32*nt + (lane&31)]
+#pragma once
+#include <stddef.h>
+
+#define LSNF_MAX_DEPTH 16
+#define LSNF_TILE 32
+#define LSNF_FRAG_FLOATS 1024 /* one (nt,kt) 32x32 fragment block */
+
+struct LsnfGeo {
+    int nz, half, width, depth, coupling;
+    int HT, WT, NZT;            // tiles of 32: half, width, 2*HT
+    // forward stream, per block
+    int fwd_panels;             // panels per block
+    int fwd_block_floats;       // panel floats per block
+    int fwd_const_floats;       // bias/const floats per block
+    // inverse stream, per block
+    int inv_panels, inv_block_floats, inv_const_floats;
+    // backward-z stream, per block
+    int bwd_panels, bwd_block_floats, bwd_const_floats;
+    // offsets (floats) into the plan buffer
+    size_t off_fwd_const, off_fwd_panels;
+    size_t off_inv_const, off_inv_panels;
+    size_t off_bwd_const, off_bwd_panels;
+    size_t off_winv;            // depth * nz*nz fp32 W^-1 (natural layout; used by d log|det W|/dW)
+    size_t total_floats;
+};
+
+static inline int lsnf_ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Chooses the kernel instantiation (HT, WT) in {(1,1),(2,2),(2,4)} that covers (half, width).
+static inline int lsnf_pick_tiles(int half, int width, int* HT, int* WT) {
+    int ht = lsnf_ceil_div(half, LSNF_TILE), wt = lsnf_ceil_div(width, LSNF_TILE);
+    if (ht <= 1 && wt <= 1) { *HT = 1; *WT = 1; return 0; }
+    if (ht <= 2 && wt <= 2) { *HT = 2; *WT = 2; return 0; }
+    if (ht <= 2 && wt <= 4) { *HT = 2; *WT = 4; return 0; }
+    return -1;
+}
+
+// Forward stages per block (affine coupling):
+//   S1  v  = Wa^T x + ca      K = NZT tiles, N = NZT tiles   (actnorm folded into the 1x1 "conv")
+//   S2  h1 = relu(W1'^T v1 + c1)   K = HT, N = WT
+//   S3  h2 = relu(W2'^T h1 + c2)   K = WT, N = WT
+//   S4  t  = W3s^T h2 + c3s        K = WT, N = HT ;  p = W3p^T h2 + c3p   K = WT, N = HT
+// Inverse stages per block:
+//   I2,I3,I4 = S2,S3,S4 (same matrices) ; I1  z = Winv'^T [v1; v2] + cinv   K = NZT, N = NZT
+// Backward-z stages per block (given g on [v1 | y2], recompute of S2..S4 uses the forward stream):
+//   B4  g_h2 = W3s g_t + W3p g_p    K = 2*HT, N = WT
+//   B3  g_h1 = W2' g_a2             K = WT,   N = WT
+//   B2  g_v1 += W1' g_a1            K = WT,   N = HT
+//   B1  g_x  = Wa [g_v1; g_v2]      K = NZT,  N = NZT
+static inline int lsnf_geo_init(LsnfGeo* g, int nz, int width, int depth, int coupling) {
+    if (nz < 2 || (nz & 1) || nz > 128 || width < 1 || width > 128 || depth < 1 || depth > LSNF_MAX_DEPTH) return -1;
+    if (coupling != 1) return -1;
+    g->nz = nz; g->half = nz / 2; g->width = width; g->depth = depth; g->coupling = coupling;
+    if (lsnf_pick_tiles(g->half, width, &g->HT, &g->WT)) return -1;
+    g->NZT = 2 * g->HT;
+    const int HT = g->HT, WT = g->WT, NZT = g->NZT;
+    g->fwd_panels = NZT + WT + WT + 2 * HT;
+    g->fwd_block_floats = LSNF_FRAG_FLOATS * (NZT * NZT + WT * HT + WT * WT + 2 * HT * WT);
+    g->fwd_const_floats = 32 * g->fwd_panels + 32;
+    g->inv_panels = NZT;                       // I1 only; I2..I4 reuse the forward panels
+    g->inv_block_floats = LSNF_FRAG_FLOATS * (NZT * NZT);
+    g->inv_const_floats = 32 * NZT;
+    g->bwd_panels = WT + WT + HT + NZT;
+    g->bwd_block_floats = LSNF_FRAG_FLOATS * (WT * 2 * HT + WT * WT + HT * WT + NZT * NZT);
+    g->bwd_const_floats = 0;
+    size_t o = 0;
+    g->off_fwd_const = o;  o += (size_t)depth * g->fwd_const_floats;
+    o = (o + 255) & ~(size_t)255;
+    g->off_fwd_panels = o; o += (size_t)depth * g->fwd_block_floats;
+    g->off_inv_const = o;  o += (size_t)depth * g->inv_const_floats;
+    o = (o + 255) & ~(size_t)255;
+    g->off_inv_panels = o; o += (size_t)depth * g->inv_block_floats;
+    g->off_bwd_const = o;
+    g->off_bwd_panels = o; o += (size_t)depth * g->bwd_block_floats;
+    g->off_winv = o;       o += (size_t)depth * nz * nz;
+    o = (o + 255) & ~(size_t)255;
+    g->total_floats = o;
+    return 0;
+}

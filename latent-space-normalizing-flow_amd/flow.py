@@ -1,0 +1,191 @@
+"""Functional host API over the C ABI: prepared weights ("plan") + forward / reverse /
+backward of the flow-prior stack on device-resident fp32 tensors.
+
+PyTorch is plumbing here (device memory, streams); every number is produced by the HIP
+kernels in csrc/.  All functions raise on CPU tensors: there is no CPU path."""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import LSNF_PARAMS_PER_BLOCK, LsnfError
+
+# order of the live tensors of one coupling block at the ABI (include/lsnf_flow.h)
+BLOCK_PARAM_KEYS = (
+    "actnorm.b", "actnorm.logs", "invertible_1x1_conv.w",
+    "f.fc_1.w", "f.fc_1.actnorm.b", "f.fc_1.actnorm.logs",
+    "f.fc_2.w", "f.fc_2.actnorm.b", "f.fc_2.actnorm.logs",
+    "f.fc_zeros.w", "f.fc_zeros.b", "f.fc_zeros.logs",
+)
+
+
+def block_prefix(i: int, level: int = 0) -> str:
+    return f"revnet2d_s.{level}.revnet2d_step_s.{i}."
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _need_cuda(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise LsnfError(f"{name} must live on the GPU (got {t.device}); this library has no CPU path")
+    if t.dtype != torch.float32:
+        raise LsnfError(f"{name} must be float32 (got {t.dtype})")
+    if not t.is_contiguous():
+        raise LsnfError(f"{name} must be contiguous")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+@dataclass
+class FlowPlan:
+    """Prepared (folded, padded, fragment-ordered) weights of one `_netF`, device resident."""
+    nz: int
+    width: int
+    depth: int
+    coupling: int
+    buf: torch.Tensor        # fp32 plan buffer
+    scratch: torch.Tensor    # float64 LU workspace (kept so re-preparation allocates nothing)
+
+    @property
+    def device(self):
+        return self.buf.device
+
+    def logabsdet(self) -> torch.Tensor:
+        """(depth,) float64: log|det W_i| computed by the Gauss-Jordan kernel."""
+        n = self.nz
+        per = n * n + 8
+        return self.scratch.view(self.depth, per)[:, n * n].clone()
+
+    def winv(self) -> torch.Tensor:
+        """(depth, nz, nz) float64 inverse of every 1x1-conv matrix."""
+        n = self.nz
+        per = n * n + 8
+        return self.scratch.view(self.depth, per)[:, : n * n].reshape(self.depth, n, n).clone()
+
+
+def alloc_plan(nz: int, width: int, depth: int, coupling: int, device) -> FlowPlan:
+    lib = _lib.load()
+    nfl = lib.lsnf_plan_floats(nz, width, depth, coupling)
+    if nfl == 0:
+        raise LsnfError(f"unsupported geometry nz={nz} width={width} depth={depth} coupling={coupling}")
+    nsc = lib.lsnf_prepare_scratch_bytes(nz, width, depth)
+    buf = torch.empty(nfl, dtype=torch.float32, device=device)
+    scratch = torch.empty(nsc // 8, dtype=torch.float64, device=device)
+    return FlowPlan(nz, width, depth, coupling, buf, scratch)
+
+
+def prepare(params: Sequence[torch.Tensor], nz: int, width: int, depth: int, coupling: int = 1,
+            plan: Optional[FlowPlan] = None) -> FlowPlan:
+    """params: depth*12 device tensors in BLOCK_PARAM_KEYS order per block.
+    Replaces the batch-independent work the reference redoes on every call (model.py:182,193,264,349)."""
+    lib = _lib.load()
+    if len(params) != depth * LSNF_PARAMS_PER_BLOCK:
+        raise LsnfError(f"expected {depth * LSNF_PARAMS_PER_BLOCK} parameter tensors, got {len(params)}")
+    half = nz // 2
+    n_out = nz if coupling == 1 else half
+    shapes = [nz, nz, nz * nz, half * width, width, width, width * width, width, width, width * n_out, n_out, n_out]
+    for i, t in enumerate(params):
+        _need_cuda(t, f"param[{i}]")
+        if t.numel() != shapes[i % LSNF_PARAMS_PER_BLOCK]:
+            raise LsnfError(f"param[{i}] ({BLOCK_PARAM_KEYS[i % 12]}) has {t.numel()} elements, "
+                            f"expected {shapes[i % 12]}")
+    dev = params[0].device
+    if plan is None:
+        plan = alloc_plan(nz, width, depth, coupling, dev)
+    arr = (ctypes.c_void_p * len(params))(*[t.data_ptr() for t in params])
+    with torch.cuda.device(dev):
+        rc = lib.lsnf_prepare(arr, nz, width, depth, coupling, _ptr(plan.buf), _ptr(plan.scratch), _stream_ptr(dev))
+    _lib.check(rc, "lsnf_prepare")
+    return plan
+
+
+def params_from_state_dict(sd, depth: int, device=None) -> List[torch.Tensor]:
+    """Pick the 12 live tensors per block out of a reference-keyed state_dict."""
+    out = []
+    for i in range(depth):
+        pre = block_prefix(i)
+        for k in BLOCK_PARAM_KEYS:
+            t = sd[pre + k]
+            if device is not None:
+                t = t.to(device)
+            out.append(t.detach().to(torch.float32).contiguous())
+    return out
+
+
+def forward(plan: FlowPlan, z: torch.Tensor, objective: Optional[torch.Tensor] = None, *,
+            first_block: int = 0, n_blocks: Optional[int] = None, want_ll: bool = True,
+            save_for_backward: bool = False, out: Optional[Tuple[torch.Tensor, ...]] = None):
+    """One launch: blocks [first_block, first_block+n_blocks) on (B, nz) rows.
+    Returns (z_out, logdet, ll or None, z_saved or None).  model.py:473-483 + train.py:317-319."""
+    lib = _lib.load()
+    _need_cuda(z, "z")
+    if z.dim() != 2 or z.shape[1] != plan.nz:
+        raise LsnfError(f"z must be (B, {plan.nz}), got {tuple(z.shape)}")
+    B = z.shape[0]
+    n_blocks = plan.depth - first_block if n_blocks is None else n_blocks
+    if objective is not None:
+        _need_cuda(objective, "objective")
+        if objective.numel() != B:
+            raise LsnfError("objective must have B elements")
+    if out is not None:
+        z_out, logdet, ll = out
+    else:
+        z_out = torch.empty_like(z)
+        logdet = torch.empty(B, dtype=torch.float32, device=z.device)
+        ll = torch.empty(B, dtype=torch.float32, device=z.device) if want_ll else None
+    saved = None
+    if save_for_backward and n_blocks > 1:
+        saved = torch.empty((n_blocks - 1, B, plan.nz), dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device):
+        rc = lib.lsnf_forward(_ptr(plan.buf), plan.nz, plan.width, plan.depth, plan.coupling, first_block, n_blocks, B,
+                              _ptr(z), _ptr(objective), _ptr(z_out), _ptr(logdet), _ptr(ll), _ptr(saved),
+                              _stream_ptr(z.device))
+    _lib.check(rc, "lsnf_forward")
+    return z_out, logdet, ll, saved
+
+
+def reverse(plan: FlowPlan, z: torch.Tensor, objective: Optional[torch.Tensor] = None):
+    """model.py:484-498: returns (z_out, objective_out) with objective_out = objective - sum log|det J|."""
+    lib = _lib.load()
+    _need_cuda(z, "z")
+    if z.dim() != 2 or z.shape[1] != plan.nz:
+        raise LsnfError(f"z must be (B, {plan.nz}), got {tuple(z.shape)}")
+    B = z.shape[0]
+    if objective is not None:
+        _need_cuda(objective, "objective")
+    z_out = torch.empty_like(z)
+    obj_out = torch.empty(B, dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device):
+        rc = lib.lsnf_reverse(_ptr(plan.buf), plan.nz, plan.width, plan.depth, plan.coupling, B,
+                              _ptr(z), _ptr(objective), _ptr(z_out), _ptr(obj_out), _stream_ptr(z.device))
+    _lib.check(rc, "lsnf_reverse")
+    return z_out, obj_out
+
+
+def backward_z(plan: FlowPlan, z_out: torch.Tensor, z_saved: Optional[torch.Tensor],
+               g_z1: Optional[torch.Tensor] = None, g_logdet: Optional[torch.Tensor] = None,
+               ll_scale: Optional[float] = None) -> torch.Tensor:
+    """dL/dz_in of the full stack (train.py:323).  Either pass upstream gradients (g_z1, g_logdet) or
+    ll_scale for L = ll_scale * sum_b ll_b (train.py:320: ll_scale = -1)."""
+    lib = _lib.load()
+    _need_cuda(z_out, "z_out")
+    B = z_out.shape[0]
+    for name, t in (("z_saved", z_saved), ("g_z1", g_z1), ("g_logdet", g_logdet)):
+        if t is not None:
+            _need_cuda(t, name)
+    g_in = torch.empty_like(z_out)
+    with torch.cuda.device(z_out.device):
+        rc = lib.lsnf_backward_z(_ptr(plan.buf), plan.nz, plan.width, plan.depth, plan.coupling, B,
+                                 _ptr(z_out), _ptr(z_saved), _ptr(g_z1), _ptr(g_logdet),
+                                 0 if ll_scale is None else 1, float(ll_scale or 0.0), _ptr(g_in),
+                                 _stream_ptr(z_out.device))
+    _lib.check(rc, "lsnf_backward_z")
+    return g_in

@@ -1,0 +1,134 @@
+"""GPU parity: HIP forward (through the C ABI) vs the golden vectors of the reference and vs the
+oracle on the same seeded inputs.  Tolerances (north_star): log-prob <= 1e-5 relative, z1 <= 1e-4 abs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden
+from oracle import flow_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+LL_REL = 1e-5
+Z_ABS = 1e-4
+
+
+def _plan(lsnf, p, g, dev):
+    nz, w, d = int(g["meta_nz"]), int(g["meta_width"]), int(g["meta_depth"])
+    return lsnf.prepare(lsnf.params_from_state_dict(p, d, dev), nz, w, d), nz, w, d
+
+
+@pytest.fixture(scope="module")
+def lsnf():
+    import lsnf_amd
+    lsnf_amd.load_library()
+    return lsnf_amd
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_prepare_logdet_and_inverse(lsnf, gpu_device, name):
+    p, g = load_golden(name)
+    plan, nz, w, d = _plan(lsnf, p, g, gpu_device)
+    lad = plan.logabsdet().cpu()
+    winv = plan.winv().cpu()
+    for i in range(d):
+        W = p[O.block_prefix(i) + "invertible_1x1_conv.w"].double()
+        ref = torch.linalg.slogdet(W)[1]
+        assert abs(lad[i].item() - ref.item()) <= 1e-10 * max(1.0, abs(ref.item())) + 1e-11
+        assert (winv[i] - torch.linalg.inv(W)).abs().max().item() <= 1e-9 * torch.linalg.inv(W).abs().max().item()
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_forward_matches_reference_golden(lsnf, gpu_device, name):
+    p, g = load_golden(name)
+    plan, nz, w, d = _plan(lsnf, p, g, gpu_device)
+    z = torch.from_numpy(g["z"]).to(gpu_device)
+    z1, ld, ll, _ = lsnf.forward(plan, z)
+    torch.cuda.synchronize()
+    z1, ld, ll = z1.cpu().numpy(), ld.cpu().numpy(), ll.cpu().numpy()
+    scale = max(1.0, np.abs(g["z1"]).max())
+    assert np.max(np.abs(ll - g["ll"]) / np.abs(g["ll"])) <= LL_REL
+    assert np.max(np.abs(ld - g["logdet"]) / np.maximum(np.abs(g["logdet"]), 1.0)) <= LL_REL
+    assert np.max(np.abs(z1 - g["z1"])) <= Z_ABS * scale
+    # and not worse than ~10x the reference's own fp32 noise against its fp64 run
+    err64 = np.max(np.abs(ll.astype(np.float64) - g["ll_f64"]) / np.abs(g["ll_f64"]))
+    assert err64 <= 5e-6
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_per_block_launches_match(lsnf, gpu_device, name):
+    """One launch per coupling block (first_block=i, n_blocks=1), chained through HBM."""
+    p, g = load_golden(name)
+    plan, nz, w, d = _plan(lsnf, p, g, gpu_device)
+    z = torch.from_numpy(g["z"]).to(gpu_device)
+    ld = torch.zeros(z.shape[0], device=gpu_device)
+    for i in range(d):
+        z, ld, _, _ = lsnf.forward(plan, z, ld, first_block=i, n_blocks=1, want_ll=False)
+        ref = g["block_z"][i]
+        assert np.max(np.abs(z.cpu().numpy() - ref)) <= Z_ABS * max(1.0, np.abs(ref).max())
+        refl = g["block_logdet"][i]
+        assert np.max(np.abs(ld.cpu().numpy() - refl) / np.maximum(np.abs(refl), 1.0)) <= LL_REL
+
+
+def test_saved_activations_are_block_outputs(lsnf, gpu_device):
+    p, g = load_golden("c3_nz128_w64_B200")
+    plan, nz, w, d = _plan(lsnf, p, g, gpu_device)
+    z = torch.from_numpy(g["z"]).to(gpu_device)
+    _, _, _, saved = lsnf.forward(plan, z, save_for_backward=True)
+    assert saved.shape == (d - 1, z.shape[0], nz)
+    for i in range(d - 1):
+        assert np.max(np.abs(saved[i].cpu().numpy() - g["block_z"][i])) <= Z_ABS * max(1.0, np.abs(g["block_z"][i]).max())
+
+
+@pytest.mark.parametrize("nz,width,B", [(128, 64, 1), (128, 64, 33), (128, 64, 129), (100, 64, 300), (64, 32, 97),
+                                        (20, 10, 130), (100, 128, 257), (2, 1, 5), (126, 127, 77)])
+def test_forward_vs_oracle_ragged(lsnf, gpu_device, nz, width, B):
+    """Seeded synthetic weights / inputs at ragged sizes (partial waves, partial workgroups, odd nz/2)."""
+    depth = 5
+    p = O.init_params(nz, width, depth, seed=nz + width)
+    z = 1.5 * torch.randn(B, nz, generator=torch.Generator().manual_seed(B))
+    obj = torch.randn(B, generator=torch.Generator().manual_seed(B + 1))
+    z1r, ldr = O.flow_forward(p, z, obj)
+    llr = O.log_prob(z1r, ldr)
+    plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
+    z1, ld, ll, _ = lsnf.forward(plan, z.to(gpu_device), obj.to(gpu_device))
+    assert ((ll.cpu() - llr).abs() / llr.abs().clamp_min(1.0)).max().item() <= LL_REL
+    assert (z1.cpu() - z1r).abs().max().item() <= Z_ABS * max(1.0, z1r.abs().max().item())
+
+
+def test_full_size_properties(lsnf, gpu_device):
+    """BASELINE.json's full size (nz=128, w=64, B=65536): size-independent properties.
+    (a) row independence: the first 4096 rows of the big launch equal a 4096-row launch bit for bit;
+    (b) a strided sample of rows equals the oracle within tolerance;
+    (c) objective is additive: forward(z, obj) == forward(z, 0) + obj."""
+    nz, width, depth, B = 128, 64, 5, 65536
+    p = O.init_params(nz, width, depth, seed=1)
+    plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
+    z = torch.randn(B, nz, generator=torch.Generator().manual_seed(1234))
+    zd = z.to(gpu_device)
+    z1, ld, ll, _ = lsnf.forward(plan, zd)
+    z1s, lds, lls, _ = lsnf.forward(plan, zd[:4096].contiguous())
+    assert torch.equal(z1[:4096], z1s) and torch.equal(ll[:4096], lls) and torch.equal(ld[:4096], lds)
+    idx = torch.arange(0, B, 127)
+    z1r, ldr, llr = O.flow_log_prob(p, z[idx])
+    assert ((ll.cpu()[idx] - llr).abs() / llr.abs()).max().item() <= LL_REL
+    assert (z1.cpu()[idx] - z1r).abs().max().item() <= Z_ABS
+    obj = torch.full((B,), 3.25, device=gpu_device)
+    _, ld2, _, _ = lsnf.forward(plan, zd, obj)
+    assert (ld2 - (ld + 3.25)).abs().max().item() <= 2e-5
+    assert torch.isfinite(ll).all()
+
+
+def test_errors_are_loud(lsnf, gpu_device):
+    p = O.init_params(8, 4, 5, seed=1)
+    plan = lsnf.prepare(lsnf.params_from_state_dict(p, 5, gpu_device), 8, 4, 5)
+    with pytest.raises(lsnf.LsnfError):
+        lsnf.forward(plan, torch.zeros(4, 8))                      # CPU tensor
+    with pytest.raises(lsnf.LsnfError):
+        lsnf.forward(plan, torch.zeros(4, 10, device=gpu_device))  # wrong nz
+    with pytest.raises(lsnf.LsnfError):
+        lsnf.forward(plan, torch.zeros(4, 8, device=gpu_device), first_block=3, n_blocks=4)
+    with pytest.raises(lsnf.LsnfError):
+        lsnf.flow.alloc_plan(130, 64, 5, 1, gpu_device)            # geometry out of range
+    z1, ld, ll, _ = lsnf.forward(plan, torch.zeros(0, 8, device=gpu_device))   # empty batch is legal
+    assert z1.shape == (0, 8) and ll.shape == (0,)
