@@ -1,6 +1,205 @@
-// placeholder until the backward kernel lands (fails loudly, no fallback)
-#include <hip/hip_runtime.h>
-#include "lsnf_layout.h"
-hipError_t lsnf_launch_backward_z(const LsnfGeo&, const float*, int, const float*, const float*, const float*, const float*, int, float, float*, int, hipStream_t) {
-    return hipErrorNotSupported;
+// lsnf_bwd.hip -- fused backward of the whole stack w.r.t. z, one launch.
+// Replaces what autograd does for train.py:316-323 (z_grad_f = d(-sum ll)/dz through
+// model.py:391-422 x f_depth): per block, last to first, with the running gradient
+// g = dL/d[z1|z2'] in VGPRs:
+//   recompute  h1,h2 (relu masks), shift t, pre-sigmoid p from the SAVED block output (z1 = v1)
+//   g_v2 = g_y2*s ; g_t = g_v2 ; g_p = (1-s)*(g_y2*y2 + g_l)      [s = sigmoid(p), y2 = (v2+t)*s]
+//   g_h2 = W3s g_t + W3p g_p ; g_a2 = g_h2 * [h2>0] ; g_h1 = W2' g_a2 ; g_a1 = g_h1 * [h1>0]
+//   g_v1 = g_v1 + W1' g_a1 ;  g_x = Wa [g_v1; g_v2]               (actnorm folded into Wa)
+// dL/dlogdet (g_l) is constant through the stack because logdet_out = logdet_in + (...).
+// Activation memory: only the block outputs (z_saved from lsnf_forward) -- the MLP is recomputed.
+#include "lsnf_device.h"
+
+namespace {
+
+template <int HT_, int WT_>
+struct BwdCfg {
+    static constexpr int HT = HT_, WT = WT_, NZT = 2 * HT_;
+    static constexpr int P1 = NZT, P2 = WT, P3 = WT, P4 = 2 * HT, NP = P1 + P2 + P3 + P4;
+    static constexpr int MAXKT = (NZT > WT ? NZT : WT);
+    static constexpr int SLOT = MAXKT * LSNF_FRAG_FLOATS;
+    static constexpr int FWD_BLOCK = LSNF_FRAG_FLOATS * (NZT * NZT + WT * HT + WT * WT + 2 * HT * WT);
+    static constexpr int FWD_CONST = 32 * NP + 32;
+    static constexpr int OFF_S2 = LSNF_FRAG_FLOATS * NZT * NZT;
+    static constexpr int OFF_S3 = OFF_S2 + LSNF_FRAG_FLOATS * WT * HT;
+    static constexpr int OFF_S4 = OFF_S3 + LSNF_FRAG_FLOATS * WT * WT;
+    // backward stream of one block: B4 (WT panels, KT=2HT), B3 (WT, KT=WT), B2 (HT, KT=WT), B1 (NZT, KT=NZT)
+    static constexpr int BWD_BLOCK = LSNF_FRAG_FLOATS * (WT * 2 * HT + WT * WT + HT * WT + NZT * NZT);
+    static constexpr int OFF_B4 = 0;
+    static constexpr int OFF_B3 = OFF_B4 + LSNF_FRAG_FLOATS * WT * 2 * HT;
+    static constexpr int OFF_B2 = OFF_B3 + LSNF_FRAG_FLOATS * WT * WT;
+    static constexpr int OFF_B1 = OFF_B2 + LSNF_FRAG_FLOATS * HT * WT;
+    // only the MLP biases are needed: S2, S3, S4 bias blocks
+    static constexpr int CONST_USED = 32 * (P2 + P3 + P4);
+};
+
+struct BwdArgs {
+    const float* fwd_consts; const float* fwd_panels; const float* bwd_panels;
+    const float* z_out; const float* z_saved; const float* g_z1; const float* g_logdet;
+    float* g_z_in;
+    float ll_scale;
+    int ll_mode, B, nz, half, depth, vec4;
+};
+
+template <class C>
+__global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_bwd_z_kernel(const BwdArgs a) {
+    constexpr int HT = C::HT, WT = C::WT, NZT = C::NZT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* cst = smem;                                   // depth * CONST_USED
+    const int tid = threadIdx.x;
+    LsnfPipe pipe;
+    pipe.buf0 = smem + a.depth * C::CONST_USED;
+    pipe.slot = C::SLOT;
+    pipe.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    pipe.lane = tid & 63;
+    const int lane = pipe.lane, m = lane & 31, h = lane >> 5;
+
+    pipe.prime<HT>(a.fwd_panels + (size_t)(a.depth - 1) * C::FWD_BLOCK + C::OFF_S2);
+    for (int i = tid; i < a.depth * C::CONST_USED; i += LSNF_WG_THREADS) {
+        const int blk = i / C::CONST_USED, r = i % C::CONST_USED;
+        cst[i] = a.fwd_consts[blk * C::FWD_CONST + 32 * C::P1 + r];
+    }
+    const long sample = ((long)blockIdx.x * LSNF_WG_WAVES + pipe.wave) * 32 + m;
+    const bool live = sample < a.B;
+    const long row = live ? sample : (long)a.B - 1;
+    const bool vec4 = a.vec4 != 0;
+
+    // upstream gradient on the stack output
+    f32x16 gx[NZT];
+    float gl;
+    if (a.ll_mode) {       // L = ll_scale * sum ll : dL/dz1 = -ll_scale * z1, dL/dlogdet = ll_scale (train.py:317-320)
+        lsnf_load_rows<HT>(gx, a.z_out, row, a.nz, a.half, h, vec4);
+#pragma unroll
+        for (int t = 0; t < NZT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gx[t][r] = -a.ll_scale * gx[t][r];
+        gl = a.ll_scale;
+    } else {
+        if (a.g_z1) lsnf_load_rows<HT>(gx, a.g_z1, row, a.nz, a.half, h, vec4);
+        else {
+#pragma unroll
+            for (int t = 0; t < NZT; ++t) gx[t] = lsnf_zero16();
+        }
+        gl = a.g_logdet ? a.g_logdet[row] : 0.0f;
+    }
+
+    for (int blk = a.depth - 1; blk >= 0; --blk) {
+        const float* cb = cst + blk * C::CONST_USED;
+        const float* gf = a.fwd_panels + (size_t)blk * C::FWD_BLOCK;
+        const float* gb = a.bwd_panels + (size_t)blk * C::BWD_BLOCK;
+        const float* gnext = blk > 0 ? a.fwd_panels + (size_t)(blk - 1) * C::FWD_BLOCK + C::OFF_S2 : nullptr;
+        const float* ysrc = (blk == a.depth - 1) ? a.z_out : a.z_saved + (size_t)blk * a.B * a.nz;
+
+        f32x16 y[NZT];     // block output [v1 | y2]
+        lsnf_load_rows<HT>(y, ysrc, row, a.nz, a.half, h, vec4);
+
+        // ---- recompute the MLP (forward panels S2..S4) ----
+        f32x16 h1[WT];
+        lsnf_static_for<WT>([&](auto nt) {
+            const float* nxt = (nt + 1 < WT) ? gf + C::OFF_S2 + (nt + 1) * HT * LSNF_FRAG_FLOATS : gf + C::OFF_S3;
+            const float* lb = (nt + 1 < WT) ? pipe.acquire<HT>(nxt) : pipe.acquire<WT>(nxt);
+            h1[nt] = lsnf_bias_init(cb + 32 * nt, h);
+            lsnf_panel_mma<HT>(h1[nt], y, lb, lane);
+            h1[nt] = lsnf_relu16(h1[nt]);
+        });
+        f32x16 h2[WT];
+        lsnf_static_for<WT>([&](auto nt) {
+            const float* nxt = (nt + 1 < WT) ? gf + C::OFF_S3 + (nt + 1) * WT * LSNF_FRAG_FLOATS : gf + C::OFF_S4;
+            const float* lb = pipe.acquire<WT>(nxt);
+            h2[nt] = lsnf_bias_init(cb + 32 * (C::P2 + nt), h);
+            lsnf_panel_mma<WT>(h2[nt], h1, lb, lane);
+            h2[nt] = lsnf_relu16(h2[nt]);
+        });
+        unsigned m1[WT], m2[WT];
+#pragma unroll
+        for (int t = 0; t < WT; ++t) m1[t] = lsnf_posmask16(h1[t]);
+        f32x16 tp[2 * HT];
+        lsnf_static_for<2 * HT>([&](auto nt) {
+            const float* lb;
+            if constexpr (nt + 1 < 2 * HT) lb = pipe.acquire<WT>(gf + C::OFF_S4 + (nt + 1) * WT * LSNF_FRAG_FLOATS);
+            else lb = pipe.acquire<2 * HT>(gb + C::OFF_B4);
+            tp[nt] = lsnf_bias_init(cb + 32 * (C::P2 + C::P3 + nt), h);
+            lsnf_panel_mma<WT>(tp[nt], h2, lb, lane);
+        });
+#pragma unroll
+        for (int t = 0; t < WT; ++t) m2[t] = lsnf_posmask16(h2[t]);
+
+        // ---- coupling backward: tp[0..HT) <- g_t (= g_v2), tp[HT..2HT) <- g_p ----
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sig, lsig;
+                lsnf_sigmoid_logsig(tp[HT + t][r], sig, lsig);
+                const float gy2 = gx[HT + t][r];
+                tp[t][r] = gy2 * sig;
+                tp[HT + t][r] = (1.0f - sig) * (gy2 * y[HT + t][r] + gl);
+            }
+        // ---- B4: g_h2 = [W3s W3p] [g_t; g_p], relu mask ----
+        f32x16 gh2[WT];
+        lsnf_static_for<WT>([&](auto nt) {
+            const float* lb;
+            if constexpr (nt + 1 < WT) lb = pipe.acquire<2 * HT>(gb + C::OFF_B4 + (nt + 1) * 2 * HT * LSNF_FRAG_FLOATS);
+            else lb = pipe.acquire<WT>(gb + C::OFF_B3);
+            gh2[nt] = lsnf_zero16();
+            lsnf_panel_mma<2 * HT>(gh2[nt], tp, lb, lane);
+            gh2[nt] = lsnf_apply_mask16(gh2[nt], m2[nt]);
+        });
+        // ---- B3: g_h1 = W2' g_a2, relu mask ----
+        f32x16 gh1[WT];
+        lsnf_static_for<WT>([&](auto nt) {
+            const float* lb = pipe.acquire<WT>((nt + 1 < WT) ? gb + C::OFF_B3 + (nt + 1) * WT * LSNF_FRAG_FLOATS : gb + C::OFF_B2);
+            gh1[nt] = lsnf_zero16();
+            lsnf_panel_mma<WT>(gh1[nt], gh2, lb, lane);
+            gh1[nt] = lsnf_apply_mask16(gh1[nt], m1[nt]);
+        });
+        // ---- B2: g_v1 = g_v1(direct) + W1' g_a1 ;  gv = [g_v1 ; g_v2] ----
+        f32x16 gv[NZT];
+        lsnf_static_for<HT>([&](auto nt) {
+            const float* lb;
+            if constexpr (nt + 1 < HT) lb = pipe.acquire<WT>(gb + C::OFF_B2 + (nt + 1) * WT * LSNF_FRAG_FLOATS);
+            else lb = pipe.acquire<NZT>(gb + C::OFF_B1);
+            gv[nt] = gx[nt];
+            lsnf_panel_mma<WT>(gv[nt], gh1, lb, lane);
+        });
+#pragma unroll
+        for (int t = 0; t < HT; ++t) gv[HT + t] = tp[t];
+        // ---- B1: g_x = Wa gv ----
+        lsnf_static_for<NZT>([&](auto nt) {
+            const float* lb;
+            if constexpr (nt + 1 < NZT) lb = pipe.acquire<NZT>(gb + C::OFF_B1 + (nt + 1) * NZT * LSNF_FRAG_FLOATS);
+            else lb = pipe.acquire<HT>(gnext);
+            gx[nt] = lsnf_zero16();
+            lsnf_panel_mma<NZT>(gx[nt], gv, lb, lane);
+        });
+    }
+    if (live) lsnf_store_rows<HT>(gx, a.g_z_in, sample, a.nz, a.half, h, vec4);
+}
+
+template <class C>
+hipError_t launch_bwd(const BwdArgs& a, hipStream_t stream) {
+    const size_t lds = ((size_t)a.depth * C::CONST_USED + 2 * (size_t)C::SLOT) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)lsnf_bwd_z_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)((a.B + LSNF_WG_SAMPLES - 1) / LSNF_WG_SAMPLES);
+    hipLaunchKernelGGL(lsnf_bwd_z_kernel<C>, dim3(grid), dim3(LSNF_WG_THREADS), lds, stream, a);
+    return hipGetLastError();
+}
+}  // namespace
+
+hipError_t lsnf_launch_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
+                                  const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
+                                  float* g_z_in, int vec4, hipStream_t stream) {
+    BwdArgs a;
+    a.fwd_consts = plan + g.off_fwd_const; a.fwd_panels = plan + g.off_fwd_panels; a.bwd_panels = plan + g.off_bwd_panels;
+    a.z_out = z_out; a.z_saved = z_saved; a.g_z1 = g_z1; a.g_logdet = g_logdet; a.g_z_in = g_z_in;
+    a.ll_scale = ll_scale; a.ll_mode = ll_mode; a.B = B; a.nz = g.nz; a.half = g.half; a.depth = g.depth; a.vec4 = vec4;
+    if (g.HT == 1 && g.WT == 1) return launch_bwd<BwdCfg<1, 1>>(a, stream);
+    if (g.HT == 2 && g.WT == 2) return launch_bwd<BwdCfg<2, 2>>(a, stream);
+    if (g.HT == 2 && g.WT == 4) return launch_bwd<BwdCfg<2, 4>>(a, stream);
+    return hipErrorInvalidValue;
 }

@@ -2,6 +2,7 @@
 // gfx950 (CDNA4) only: wave64, v_mfma_f32_32x32x2_f32, LDS-DMA (global_load_lds_dwordx4).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "lsnf_layout.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -151,4 +152,51 @@ __device__ __forceinline__ void lsnf_store_rows(const f32x16* x, float* __restri
             }
         }
     }
+}
+
+// ---- double-buffered weight-panel pipeline with a run-time buffer parity -------------------------
+// acquire<KT_NEXT>(next): (1) wait for my LDS-DMA + workgroup barrier: the panel issued one acquire
+// ago is now complete in buf[cur] and every wave is done with buf[cur^1]; (2) start the LDS-DMA of
+// the NEXT panel (KT_NEXT k-tiles at `next`, or nothing if next == nullptr) into buf[cur^1];
+// (3) return buf[cur] for the MFMAs and flip.  The very first panel is issued with prime<KT>().
+struct LsnfPipe {
+    float* buf0;
+    int slot;     // floats per buffer
+    int cur;      // wave-uniform
+    int wave, lane;
+
+    template <int KT>
+    __device__ __forceinline__ void prime(const float* src) {
+        lsnf_issue_panel<KT>(src, buf0, wave, lane);
+        cur = 0;
+    }
+    template <int KT_NEXT>
+    __device__ __forceinline__ const float* acquire(const float* next) {
+        lsnf_panel_barrier();
+        if (next != nullptr) lsnf_issue_panel<KT_NEXT>(next, buf0 + (cur ^ 1) * slot, wave, lane);
+        const float* ready = buf0 + cur * slot;
+        cur ^= 1;
+        return ready;
+    }
+};
+
+template <int N, class F, int I = 0>
+__device__ __forceinline__ void lsnf_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        lsnf_static_for<N, F, I + 1>(static_cast<F&&>(f));
+    }
+}
+
+// bit r of the result = (a[r] > 0): relu mask of one tile, for the backward pass
+__device__ __forceinline__ unsigned lsnf_posmask16(const f32x16& a) {
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m |= (a[r] > 0.0f ? 1u : 0u) << r;
+    return m;
+}
+__device__ __forceinline__ f32x16 lsnf_apply_mask16(f32x16 a, unsigned m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = ((m >> r) & 1u) ? a[r] : 0.0f;
+    return a;
 }

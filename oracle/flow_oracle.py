@@ -200,6 +200,28 @@ def grad_neg_mean_ll_wrt_params(p: Params, z: Tensor, coupling: int = 1) -> Dict
     return dict(zip(keys, grads))
 
 
+def relu_margin(p: Params, z: Tensor) -> Tensor:
+    """(B,) float64: the smallest |pre-activation| any ReLU of the stack sees for each row, in
+    float64.  d ll/dz is DISCONTINUOUS where a pre-activation crosses zero (model.py:307-308), so
+    for a row whose margin is below fp32 rounding noise (~1e-6) two correct fp32 implementations may
+    legitimately return gradients that differ by O(1e-3).  Tests use this to set such rows aside."""
+    p64 = to_dtype(p, torch.float64)
+    zz = z.double()
+    ld = torch.zeros(zz.shape[0], dtype=torch.float64)
+    margin = torch.full((zz.shape[0],), float("inf"), dtype=torch.float64)
+    for i in range(depth_of(p64)):
+        pre = block_prefix(i)
+        n_z = zz.shape[-1]
+        x = actnorm_fwd(zz, p64[pre + "actnorm.b"], p64[pre + "actnorm.logs"])
+        v1 = torch.matmul(x, p64[pre + "invertible_1x1_conv.w"])[:, : n_z // 2]
+        a1 = actnorm_fwd(torch.matmul(v1, p64[pre + "f.fc_1.w"]), p64[pre + "f.fc_1.actnorm.b"], p64[pre + "f.fc_1.actnorm.logs"])
+        a2 = actnorm_fwd(torch.matmul(torch.relu(a1), p64[pre + "f.fc_2.w"]), p64[pre + "f.fc_2.actnorm.b"],
+                         p64[pre + "f.fc_2.actnorm.logs"])
+        margin = torch.minimum(margin, torch.minimum(a1.abs().min(1).values, a2.abs().min(1).values))
+        zz, ld = block_fwd(p64, i, zz, ld)
+    return margin
+
+
 def is_live_param(key: str) -> bool:
     """Parameters that get a gradient in the reference: everything except
     fc_1.b / fc_2.b (unused, model.py:319,327-330) and the '.bias' alias (model.py:231)."""

@@ -1,0 +1,126 @@
+"""GPU parity of the reverse (sampling) kernel and the backward-w.r.t.-z kernel, through the C ABI,
+against the reference's golden vectors and the oracle's autograd."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden
+from oracle import flow_oracle as O
+
+pytestmark = pytest.mark.gpu
+KINK = 2e-6   # see oracle.flow_oracle.relu_margin
+
+
+@pytest.fixture(scope="module")
+def lsnf():
+    import lsnf_amd
+    lsnf_amd.load_library()
+    return lsnf_amd
+
+
+def _plan(lsnf, p, g, dev):
+    nz, w, d = int(g["meta_nz"]), int(g["meta_width"]), int(g["meta_depth"])
+    return lsnf.prepare(lsnf.params_from_state_dict(p, d, dev), nz, w, d)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_reverse_matches_reference_golden(lsnf, gpu_device, name):
+    p, g = load_golden(name)
+    plan = _plan(lsnf, p, g, gpu_device)
+    x, obj = lsnf.reverse(plan, torch.from_numpy(g["rev_in"]).to(gpu_device))
+    x, negobj = x.cpu().numpy(), -obj.cpu().numpy()          # reference returns -objective (model.py:498)
+    scale = max(1.0, np.abs(g["rev_out"]).max())
+    assert np.max(np.abs(x - g["rev_out"])) <= 5e-4 * scale
+    assert np.max(np.abs(negobj - g["rev_negobj"]) / np.maximum(np.abs(g["rev_negobj"]), 1.0)) <= 1e-5
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_roundtrip_forward_reverse(lsnf, gpu_device, name):
+    """forward o reverse = identity and the two log-dets cancel (the flow's own self-check)."""
+    p, g = load_golden(name)
+    plan = _plan(lsnf, p, g, gpu_device)
+    z = torch.from_numpy(g["z"]).to(gpu_device)
+    z1, ld, _, _ = lsnf.forward(plan, z)
+    back, obj = lsnf.reverse(plan, z1, ld)
+    zmax = max(1.0, z.abs().max().item())
+    assert (back - z).abs().max().item() <= 2e-3 * zmax
+    assert (obj.abs() / ld.abs().clamp_min(1.0)).max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_grad_z_matches_reference_golden(lsnf, gpu_device, name):
+    """d(-sum ll)/dz (train.py:320-323), fused ll_mode."""
+    p, g = load_golden(name)
+    plan = _plan(lsnf, p, g, gpu_device)
+    z = torch.from_numpy(g["z"]).to(gpu_device)
+    z1, ld, ll, saved = lsnf.forward(plan, z, save_for_backward=True)
+    gz = lsnf.backward_z(plan, z1, saved, ll_scale=-1.0).cpu().numpy()
+    ref = g["grad_z"]
+    # rows sitting on a ReLU kink (float64 pre-activation < 2e-6) have no well-defined fp32 gradient
+    ok = (O.relu_margin(p, torch.from_numpy(g["z"])) > KINK).numpy()
+    assert ok.sum() >= 0.97 * len(ok)
+    assert np.linalg.norm(gz[ok] - ref[ok]) / np.linalg.norm(ref[ok]) <= 1e-5
+    assert np.max(np.abs(gz[ok] - ref[ok])) <= 1e-4 * max(1.0, np.abs(ref).max())
+    # a kink row may flip one ReLU: still the gradient of a neighbouring linear piece, hence close
+    assert np.max(np.abs(gz - ref)) <= 2e-2 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("nz,width,B", [(128, 64, 130), (100, 64, 77), (100, 128, 50), (20, 10, 33), (2, 1, 3)])
+def test_backward_general_upstream_vs_oracle(lsnf, gpu_device, nz, width, B):
+    """Arbitrary upstream gradients (g_z1, g_logdet) against autograd over the oracle."""
+    depth = 5
+    p = O.init_params(nz, width, depth, seed=3 * nz + width)
+    gen = torch.Generator().manual_seed(B)
+    z = torch.randn(B, nz, generator=gen)
+    gz1 = torch.randn(B, nz, generator=gen)
+    gld = torch.randn(B, generator=gen)
+    zz = z.clone().requires_grad_(True)
+    z1r, ldr = O.flow_forward(p, zz, torch.zeros(B))
+    (ref,) = torch.autograd.grad((z1r * gz1).sum() + (ldr * gld).sum(), zz)
+    plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
+    z1, ld, _, saved = lsnf.forward(plan, z.to(gpu_device), save_for_backward=True, want_ll=False)
+    ok = O.relu_margin(p, z) > KINK
+    got = lsnf.backward_z(plan, z1, saved, gz1.to(gpu_device), gld.to(gpu_device)).cpu()
+    assert ((got - ref)[ok].norm() / ref[ok].norm()).item() <= 1e-5
+    # only one of the two upstream gradients
+    z1r, ldr = O.flow_forward(p, zz, torch.zeros(B))
+    (ref2,) = torch.autograd.grad((ldr * gld).sum(), zz)
+    got2 = lsnf.backward_z(plan, z1, saved, None, gld.to(gpu_device)).cpu()
+    assert ((got2 - ref2)[ok].norm() / ref2[ok].norm()).item() <= 1e-5
+
+
+def test_langevin_trajectory_golden(lsnf, gpu_device):
+    """Noise-free K-step Langevin trajectory captured from the reference (train.py:311-326) with the
+    generator's gradient replayed from the fixture: pins the caller-side update around the flow."""
+    p, g = load_golden("langevin_nz100_w64_B16_K3")
+    plan = _plan(lsnf, p, g, gpu_device)
+    z = torch.from_numpy(g["z0"]).to(gpu_device)
+    s = float(g["step_size"])
+    for k in range(g["traj"].shape[0]):
+        z1, ld, ll, saved = lsnf.forward(plan, z, save_for_backward=True)
+        gf = lsnf.backward_z(plan, z1, saved, ll_scale=-1.0)
+        f = -ll.sum().item()
+        assert abs(f - g["f_log_lkhd"][k]) <= 1e-5 * abs(g["f_log_lkhd"][k])
+        assert np.linalg.norm(gf.cpu().numpy() - g["grad_f"][k]) <= 1e-5 * np.linalg.norm(g["grad_f"][k])
+        z = z - 0.5 * s * s * (torch.from_numpy(g["grad_g"][k]).to(gpu_device) + gf)
+        assert np.max(np.abs(z.cpu().numpy() - g["traj"][k])) <= 2e-5
+
+
+def test_full_size_backward_properties(lsnf, gpu_device):
+    """B=65536, nz=128: (a) linearity of the backward in the upstream gradient, (b) rows independent,
+    (c) sampled rows vs the oracle."""
+    nz, width, depth, B = 128, 64, 5, 65536
+    p = O.init_params(nz, width, depth, seed=1)
+    plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
+    z = torch.randn(B, nz, generator=torch.Generator().manual_seed(99))
+    zd = z.to(gpu_device)
+    z1, ld, ll, saved = lsnf.forward(plan, zd, save_for_backward=True)
+    g = lsnf.backward_z(plan, z1, saved, ll_scale=-1.0)
+    g2 = lsnf.backward_z(plan, z1, saved, ll_scale=-2.0)
+    assert (g2 - 2 * g).abs().max().item() <= 1e-4 * g.abs().max().item()
+    ga = lsnf.backward_z(plan, z1, saved, z1.clone(), torch.full((B,), -1.0, device=gpu_device))
+    assert torch.equal(ga, g)          # explicit upstream (z1, -1) == ll_mode(-1), bit for bit
+    idx = torch.arange(5, B, 4099)
+    ref = O.grad_neg_sum_ll_wrt_z(p, z[idx])
+    ok = O.relu_margin(p, z[idx]) > KINK
+    assert ((g.cpu()[idx] - ref)[ok].norm() / ref[ok].norm()).item() <= 1e-5
