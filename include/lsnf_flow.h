@@ -115,6 +115,24 @@ int lsnf_backward_z(const float* plan, int nz, int width, int depth, int couplin
                     const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
                     float* g_z_in, void* stream);
 
+/* ---- backward w.r.t. the parameters: replaces `loss_f.backward()` (train.py:406-411) --------
+ * Gradients of L w.r.t. the 12 live tensors of every block (same order as lsnf_prepare), for the
+ * upstream gradients described under lsnf_backward_z (train.py:410: L = -mean ll -> ll_mode=1,
+ * ll_scale = -1/B).  Includes d log|det W|/dW = W^-T (model.py:182) and the actnorm log-det terms.
+ *   params_host : HOST array of depth*12 DEVICE pointers to the raw parameters (read only)
+ *   grads_host  : HOST array of depth*12 DEVICE pointers that receive the gradients (a NULL entry
+ *                 skips that tensor); shapes as the parameters
+ *   z_in        : (B, nz) input of the stack; z_out / z_saved as written by lsnf_forward
+ *   g_z_in      : NULL, or (B, nz) to also receive dL/dz_in (same values as lsnf_backward_z)
+ *   workspace   : lsnf_backward_params_workspace_floats() floats, 16-byte aligned.
+ * Sums over the batch use fp32 atomics when B > 1024 (order, hence last bits, may vary run to run). */
+size_t lsnf_backward_params_workspace_floats(int nz, int width, int depth, int B);
+int lsnf_backward_params(const float* plan, const float* const* params_host, float* const* grads_host,
+                         int nz, int width, int depth, int coupling, int B,
+                         const float* z_in, const float* z_out, const float* z_saved,
+                         const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
+                         float* g_z_in, float* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,11 @@ hipError_t lsnf_launch_reverse(const LsnfGeo& g, const float* plan, int B, const
                                float* z_out, float* objective_out, int vec4, hipStream_t stream);
 hipError_t lsnf_launch_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
                                   const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
-                                  float* g_z_in, int vec4, hipStream_t stream);
+                                  float* g_z_in, float* dump, float* gl_total, int vec4, hipStream_t stream);
+hipError_t lsnf_launch_backward_params(const LsnfGeo& g, const float* plan, const float* const* params_host,
+                                       float* const* grads_host, int B, const float* z_in, const float* z_out,
+                                       const float* z_saved, const float* g_z1, const float* g_logdet, int ll_mode,
+                                       float ll_scale, float* g_z_in, float* workspace, int vec4, hipStream_t stream);
 
 namespace {
 thread_local char g_err[512] = "";
@@ -141,9 +145,39 @@ int lsnf_backward_z(const float* plan, int nz, int width, int depth, int couplin
     if (B == 0) return LSNF_OK;
     const int vec4 = (g.half % 4 == 0) && aligned16(z_out) && aligned16(g_z_in) && (z_saved == nullptr || aligned16(z_saved)) &&
                      (g_z1 == nullptr || aligned16(g_z1));
-    hipError_t e = lsnf_launch_backward_z(g, plan, B, z_out, z_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, vec4,
-                                          (hipStream_t)stream);
+    hipError_t e = lsnf_launch_backward_z(g, plan, B, z_out, z_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, nullptr,
+                                          nullptr, vec4, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "lsnf_backward_z launch");
+    return LSNF_OK;
+}
+
+size_t lsnf_backward_params_workspace_floats(int nz, int width, int depth, int B) {
+    LsnfGeo g;
+    if (lsnf_geo_init(&g, nz, width, depth, 1) || B < 0) return 0;
+    return lsnf_params_workspace_floats(nz, width, depth, B);
+}
+
+int lsnf_backward_params(const float* plan, const float* const* params_host, float* const* grads_host, int nz, int width,
+                         int depth, int coupling, int B, const float* z_in, const float* z_out, const float* z_saved,
+                         const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale, float* g_z_in,
+                         float* workspace, void* stream) {
+    LsnfGeo g;
+    if (int rc = geo_or_fail(&g, nz, width, depth, coupling)) return rc;
+    if (B < 1 || B > (1 << 28)) return fail(LSNF_E_ARG, "lsnf_backward_params: B=%d out of range", B);
+    if (!plan || !params_host || !grads_host || !z_in || !z_out || !workspace || (depth > 1 && !z_saved))
+        return fail(LSNF_E_ARG, "lsnf_backward_params: NULL argument");
+    if (!aligned16(plan) || !aligned16(workspace)) return fail(LSNF_E_ARG, "lsnf_backward_params: plan/workspace must be 16-byte aligned");
+    for (int i = 0; i < depth * LSNF_PARAMS_PER_BLOCK; ++i) {
+        if (!params_host[i] || !aligned4(params_host[i]) || !aligned4(grads_host[i]))
+            return fail(LSNF_E_ARG, "lsnf_backward_params: parameter/gradient pointer %d is NULL or misaligned", i);
+    }
+    if (!aligned4(z_in) || !aligned4(z_out) || !aligned4(z_saved) || !aligned4(g_z1) || !aligned4(g_logdet) || !aligned4(g_z_in))
+        return fail(LSNF_E_ARG, "lsnf_backward_params: tensors must be 4-byte aligned");
+    const int vec4 = (g.half % 4 == 0) && aligned16(z_out) && (g_z_in == nullptr || aligned16(g_z_in)) &&
+                     (z_saved == nullptr || aligned16(z_saved)) && (g_z1 == nullptr || aligned16(g_z1));
+    hipError_t e = lsnf_launch_backward_params(g, plan, params_host, grads_host, B, z_in, z_out, z_saved, g_z1, g_logdet,
+                                               ll_mode, ll_scale, g_z_in, workspace, vec4, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "lsnf_backward_params launch");
     return LSNF_OK;
 }
 

@@ -36,12 +36,37 @@ struct BwdCfg {
 struct BwdArgs {
     const float* fwd_consts; const float* fwd_panels; const float* bwd_panels;
     const float* z_out; const float* z_saved; const float* g_z1; const float* g_logdet;
-    float* g_z_in;
+    float* g_z_in;          // may be NULL when only parameter gradients are wanted
+    float* dump;            // DUMP variant: per-block intermediates for the parameter gradients (lsnf_layout.h)
+    float* gl_total;        // DUMP variant: += sum_b dL/dlogdet_b
     float ll_scale;
-    int ll_mode, B, nz, half, depth, vec4;
+    int ll_mode, B, nz, half, width, depth, vec4;
 };
 
-template <class C>
+// plain-pad tiles (feature f = 32*t + o(r,h), valid f < ncols) -> dense (B, ncols) row-major
+template <int T>
+__device__ __forceinline__ void store_plain(const f32x16* x, float* __restrict__ dst, long row, int ncols, int h) {
+    float* d = dst + row * (long)ncols;
+    const bool v4 = (ncols & 3) == 0;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f0 = 32 * t + 8 * g + 4 * h;
+            if (v4) {
+                if (f0 < ncols) {
+                    f32x4 v = {x[t][4 * g + 0], x[t][4 * g + 1], x[t][4 * g + 2], x[t][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(d + f0) = v;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (f0 + j < ncols) d[f0 + j] = x[t][4 * g + j];
+            }
+        }
+}
+
+template <class C, bool DUMP>
 __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_bwd_z_kernel(const BwdArgs a) {
     constexpr int HT = C::HT, WT = C::WT, NZT = C::NZT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -82,6 +107,13 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_bwd_z_kernel(const Bw
         }
         gl = a.g_logdet ? a.g_logdet[row] : 0.0f;
     }
+    if constexpr (DUMP) {   // G = sum_b dL/dlogdet_b : one atomic per wave
+        float t = (live && h == 0) ? gl : 0.0f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        if (lane == 0) atomicAdd(a.gl_total, t);
+    }
+    const LsnfDumpLayout dl = lsnf_dump_layout(a.B, a.nz, a.width);
 
     for (int blk = a.depth - 1; blk >= 0; --blk) {
         const float* cb = cst + blk * C::CONST_USED;
@@ -123,6 +155,14 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_bwd_z_kernel(const Bw
         });
 #pragma unroll
         for (int t = 0; t < WT; ++t) m2[t] = lsnf_posmask16(h2[t]);
+        float* dmp = nullptr;
+        if constexpr (DUMP) {
+            dmp = a.dump + (size_t)blk * dl.per_block;
+            if (live) {
+                store_plain<WT>(h1, dmp + dl.off_h1, sample, a.width, h);
+                store_plain<WT>(h2, dmp + dl.off_h2, sample, a.width, h);
+            }
+        }
 
         // ---- coupling backward: tp[0..HT) <- g_t (= g_v2), tp[HT..2HT) <- g_p ----
 #pragma unroll
@@ -135,6 +175,12 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_bwd_z_kernel(const Bw
                 tp[t][r] = gy2 * sig;
                 tp[HT + t][r] = (1.0f - sig) * (gy2 * y[HT + t][r] + gl);
             }
+        if constexpr (DUMP) {
+            if (live) {
+                store_plain<HT>(tp, dmp + dl.off_gt, sample, a.half, h);
+                store_plain<HT>(tp + HT, dmp + dl.off_gp, sample, a.half, h);
+            }
+        }
         // ---- B4: g_h2 = [W3s W3p] [g_t; g_p], relu mask ----
         f32x16 gh2[WT];
         lsnf_static_for<WT>([&](auto nt) {
@@ -145,6 +191,7 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_bwd_z_kernel(const Bw
             lsnf_panel_mma<2 * HT>(gh2[nt], tp, lb, lane);
             gh2[nt] = lsnf_apply_mask16(gh2[nt], m2[nt]);
         });
+        if constexpr (DUMP) { if (live) store_plain<WT>(gh2, dmp + dl.off_ga2, sample, a.width, h); }
         // ---- B3: g_h1 = W2' g_a2, relu mask ----
         f32x16 gh1[WT];
         lsnf_static_for<WT>([&](auto nt) {
@@ -153,6 +200,7 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_bwd_z_kernel(const Bw
             lsnf_panel_mma<WT>(gh1[nt], gh2, lb, lane);
             gh1[nt] = lsnf_apply_mask16(gh1[nt], m1[nt]);
         });
+        if constexpr (DUMP) { if (live) store_plain<WT>(gh1, dmp + dl.off_ga1, sample, a.width, h); }
         // ---- B2: g_v1 = g_v1(direct) + W1' g_a1 ;  gv = [g_v1 ; g_v2] ----
         f32x16 gv[NZT];
         lsnf_static_for<HT>([&](auto nt) {
@@ -164,6 +212,7 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_bwd_z_kernel(const Bw
         });
 #pragma unroll
         for (int t = 0; t < HT; ++t) gv[HT + t] = tp[t];
+        if constexpr (DUMP) { if (live) lsnf_store_rows<HT>(gv, dmp + dl.off_gv, sample, a.nz, a.half, h, false); }
         // ---- B1: g_x = Wa gv ----
         lsnf_static_for<NZT>([&](auto nt) {
             const float* lb;
@@ -173,33 +222,43 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_bwd_z_kernel(const Bw
             lsnf_panel_mma<NZT>(gx[nt], gv, lb, lane);
         });
     }
-    if (live) lsnf_store_rows<HT>(gx, a.g_z_in, sample, a.nz, a.half, h, vec4);
+    if (live && a.g_z_in) lsnf_store_rows<HT>(gx, a.g_z_in, sample, a.nz, a.half, h, vec4);
 }
 
-template <class C>
+template <class C, bool DUMP>
 hipError_t launch_bwd(const BwdArgs& a, hipStream_t stream) {
     const size_t lds = ((size_t)a.depth * C::CONST_USED + 2 * (size_t)C::SLOT) * sizeof(float);
+    auto kern = lsnf_bwd_z_kernel<C, DUMP>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)lsnf_bwd_z_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const unsigned grid = (unsigned)((a.B + LSNF_WG_SAMPLES - 1) / LSNF_WG_SAMPLES);
-    hipLaunchKernelGGL(lsnf_bwd_z_kernel<C>, dim3(grid), dim3(LSNF_WG_THREADS), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(LSNF_WG_THREADS), lds, stream, a);
     return hipGetLastError();
 }
 }  // namespace
 
+// dump == nullptr: plain backward w.r.t. z.  dump != nullptr: also writes the per-block intermediates
+// (and accumulates sum dL/dlogdet into gl_total) that lsnf_params.hip turns into parameter gradients.
 hipError_t lsnf_launch_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
                                   const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
-                                  float* g_z_in, int vec4, hipStream_t stream) {
+                                  float* g_z_in, float* dump, float* gl_total, int vec4, hipStream_t stream) {
     BwdArgs a;
+    a.dump = dump; a.gl_total = gl_total; a.width = g.width;
     a.fwd_consts = plan + g.off_fwd_const; a.fwd_panels = plan + g.off_fwd_panels; a.bwd_panels = plan + g.off_bwd_panels;
     a.z_out = z_out; a.z_saved = z_saved; a.g_z1 = g_z1; a.g_logdet = g_logdet; a.g_z_in = g_z_in;
     a.ll_scale = ll_scale; a.ll_mode = ll_mode; a.B = B; a.nz = g.nz; a.half = g.half; a.depth = g.depth; a.vec4 = vec4;
-    if (g.HT == 1 && g.WT == 1) return launch_bwd<BwdCfg<1, 1>>(a, stream);
-    if (g.HT == 2 && g.WT == 2) return launch_bwd<BwdCfg<2, 2>>(a, stream);
-    if (g.HT == 2 && g.WT == 4) return launch_bwd<BwdCfg<2, 4>>(a, stream);
+    if (dump) {
+        if (g.HT == 1 && g.WT == 1) return launch_bwd<BwdCfg<1, 1>, true>(a, stream);
+        if (g.HT == 2 && g.WT == 2) return launch_bwd<BwdCfg<2, 2>, true>(a, stream);
+        if (g.HT == 2 && g.WT == 4) return launch_bwd<BwdCfg<2, 4>, true>(a, stream);
+    } else {
+        if (g.HT == 1 && g.WT == 1) return launch_bwd<BwdCfg<1, 1>, false>(a, stream);
+        if (g.HT == 2 && g.WT == 2) return launch_bwd<BwdCfg<2, 2>, false>(a, stream);
+        if (g.HT == 2 && g.WT == 4) return launch_bwd<BwdCfg<2, 4>, false>(a, stream);
+    }
     return hipErrorInvalidValue;
 }

@@ -94,3 +94,42 @@ static inline int lsnf_geo_init(LsnfGeo* g, int nz, int width, int depth, int co
     g->total_floats = o;
     return 0;
 }
+
+// ---- workspace of the parameter-gradient path (lsnf_backward_params) -----------------------------
+// [0,4)                 : G = sum_b dL/dlogdet_b (+3 pad)
+// folded gradients      : depth * LsnfFoldLayout.per_block floats (zeroed every call, accumulated by atomics)
+// dump                  : depth * LsnfDumpLayout.per_block floats (per-sample intermediates of the backward)
+#define LSNF_AL4(x) (((x) + 3) & ~(size_t)3)
+struct LsnfDumpLayout { size_t off_gv, off_ga1, off_ga2, off_gt, off_gp, off_h1, off_h2, per_block; };
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline LsnfDumpLayout lsnf_dump_layout(int B, int nz, int width) {
+    LsnfDumpLayout d; size_t o = 0; const size_t b = (size_t)B; const int half = nz / 2;
+    d.off_gv = o;  o = LSNF_AL4(o + b * nz);
+    d.off_ga1 = o; o = LSNF_AL4(o + b * width);
+    d.off_ga2 = o; o = LSNF_AL4(o + b * width);
+    d.off_gt = o;  o = LSNF_AL4(o + b * half);
+    d.off_gp = o;  o = LSNF_AL4(o + b * half);
+    d.off_h1 = o;  o = LSNF_AL4(o + b * width);
+    d.off_h2 = o;  o = LSNF_AL4(o + b * width);
+    d.per_block = o;
+    return d;
+}
+struct LsnfFoldLayout { int dWa, dca, dW1, dc1, dW2, dc2, dW3s, dc3s, dW3p, dc3p, per_block; };
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline LsnfFoldLayout lsnf_fold_layout(int nz, int width) {
+    LsnfFoldLayout f; int o = 0; const int half = nz / 2, w = width;
+    f.dWa = o; o += nz * nz;   f.dca = o; o += nz;
+    f.dW1 = o; o += half * w;  f.dc1 = o; o += w;
+    f.dW2 = o; o += w * w;     f.dc2 = o; o += w;
+    f.dW3s = o; o += w * half; f.dc3s = o; o += half;
+    f.dW3p = o; o += w * half; f.dc3p = o; o += half;
+    f.per_block = (o + 3) & ~3;
+    return f;
+}
+static inline size_t lsnf_params_workspace_floats(int nz, int width, int depth, int B) {
+    return 4 + (size_t)depth * lsnf_fold_layout(nz, width).per_block + (size_t)depth * lsnf_dump_layout(B, nz, width).per_block;
+}

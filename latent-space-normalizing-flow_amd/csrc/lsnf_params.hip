@@ -1,0 +1,194 @@
+// lsnf_params.hip -- parameter gradients of the flow stack (replaces autograd of train.py:406-411,
+// `loss_f.backward()` into the 60 live tensors of _netF).
+//
+// Three steps on one stream:
+//  (1) lsnf_bwd_z_kernel<DUMP>  (lsnf_bwd.hip): the fused backward, which additionally writes, per block,
+//      the per-sample gradients at every GEMM output (g_v, g_a1, g_a2, g_t, g_p) and the recomputed
+//      hidden activations (h1, h2), and accumulates G = sum_b dL/dlogdet_b.
+//  (2) lsnf_tn_gemm_kernel: dM = A^T G contracted over the batch (fp32 MFMA, operands loaded straight
+//      from HBM in fragment layout -- rows are contiguous along the feature index, which is the lane
+//      index of both operands), plus the column sums of G (bias gradients); split over sample chunks,
+//      accumulated with float atomics into the zero-initialised "folded" gradient buffer.
+//  (3) lsnf_unfold_kernel: chain rule from the folded matrices (Wa = diag(e^{3s}) W, W1' = W1 diag(e^{3s1}),
+//      ..., interleaved fc_zeros columns) back to the reference's raw parameters, incl.
+//      d log|det W| / dW = W^-T (model.py:182) and d sum(3 logs)/d logs = 3 (model.py:264,273).
+#include <hip/hip_runtime.h>
+#include "lsnf_layout.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct LsnfParamPtrs { const float* p[LSNF_MAX_DEPTH * 12]; };
+struct LsnfGradPtrs { float* p[LSNF_MAX_DEPTH * 12]; };
+enum { P_AB = 0, P_ALOGS, P_W, P_W1, P_B1, P_LOGS1, P_W2, P_B2, P_LOGS2, P_W3, P_B3, P_LOGS3 };
+
+hipError_t lsnf_launch_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
+                                  const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
+                                  float* g_z_in, float* dump, float* gl_total, int vec4, hipStream_t stream);
+
+namespace {
+
+struct TnArgs {
+    const float* z_in; const float* z_out; const float* z_saved;
+    const float* dump; float* fold;
+    int B, nz, half, width, depth, chunk;
+};
+
+// task = blk*5 + which: 0 dWa (A = block input x, G = g_v) ; 1 dW1' (A = v1, G = g_a1) ; 2 dW2' (A = h1, G = g_a2)
+//                       3 dW3s (A = h2, G = g_t) ; 4 dW3p (A = h2, G = g_p)
+__global__ __launch_bounds__(256) void lsnf_tn_gemm_kernel(const TnArgs a) {
+    const int task = blockIdx.x, blk = task / 5, which = task % 5;
+    const LsnfDumpLayout dl = lsnf_dump_layout(a.B, a.nz, a.width);
+    const LsnfFoldLayout fl = lsnf_fold_layout(a.nz, a.width);
+    const float* dmp = a.dump + (size_t)blk * dl.per_block;
+    float* fold = a.fold + (size_t)blk * fl.per_block;
+    const float* yblk = (blk == a.depth - 1) ? a.z_out : a.z_saved + (size_t)blk * a.B * a.nz;       // block output
+    const float* xblk = (blk == 0) ? a.z_in : a.z_saved + (size_t)(blk - 1) * a.B * a.nz;            // block input
+    const float *A, *G; int lda, ldg, K, N; float *C, *cs;
+    switch (which) {
+    case 0: A = xblk; lda = a.nz; K = a.nz; G = dmp + dl.off_gv; ldg = a.nz; N = a.nz; C = fold + fl.dWa; cs = fold + fl.dca; break;
+    case 1: A = yblk; lda = a.nz; K = a.half; G = dmp + dl.off_ga1; ldg = a.width; N = a.width; C = fold + fl.dW1; cs = fold + fl.dc1; break;
+    case 2: A = dmp + dl.off_h1; lda = a.width; K = a.width; G = dmp + dl.off_ga2; ldg = a.width; N = a.width; C = fold + fl.dW2; cs = fold + fl.dc2; break;
+    case 3: A = dmp + dl.off_h2; lda = a.width; K = a.width; G = dmp + dl.off_gt; ldg = a.half; N = a.half; C = fold + fl.dW3s; cs = fold + fl.dc3s; break;
+    default: A = dmp + dl.off_h2; lda = a.width; K = a.width; G = dmp + dl.off_gp; ldg = a.half; N = a.half; C = fold + fl.dW3p; cs = fold + fl.dc3p; break;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = lane & 31, kk = lane >> 5;
+    const int kcol = 32 * wave + i;              // this wave owns k-tile `wave` (K <= 128 -> <= 4 tiles)
+    if (32 * wave >= K) return;                  // wave-uniform
+    const bool kok = kcol < K;
+    const int NT = (N + 31) / 32;
+    f32x16 acc[4];
+    float csum[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { csum[t] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f; }
+    const int m_begin = blockIdx.y * a.chunk;
+    const int m_end = min(a.B, m_begin + a.chunk);
+    for (int m0 = m_begin; m0 < m_end; m0 += 2) {
+        const int m = m0 + kk;
+        const bool mok = m < m_end;
+        const float av = (mok && kok) ? A[(size_t)m * lda + kcol] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < NT) {
+                const int ncol = 32 * t + i;
+                const float gv = (mok && ncol < N) ? G[(size_t)m * ldg + ncol] : 0.f;
+                csum[t] += gv;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, gv, acc[t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (t < NT) {
+            const int ncol = 32 * t + i;
+            if (ncol < N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int krow = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                    if (krow < K) atomicAdd(&C[(size_t)krow * N + ncol], acc[t][r]);
+                }
+            }
+            if (wave == 0) {   // column sums of G (bias gradients), once per task
+                const float s = csum[t] + __shfl_xor(csum[t], 32, 64);
+                if (kk == 0 && ncol < N) atomicAdd(&cs[ncol], s);
+            }
+        }
+    }
+}
+
+// one workgroup per block: raw-parameter gradients from the folded ones
+__global__ __launch_bounds__(256) void lsnf_unfold_kernel(LsnfParamPtrs pp, LsnfGradPtrs gp, const float* fold_all,
+                                                          const float* gl_total, const float* winv_all, int nz, int width) {
+    const int blk = blockIdx.x, tid = threadIdx.x;
+    const int half = nz / 2, w = width;
+    const LsnfFoldLayout fl = lsnf_fold_layout(nz, width);
+    const float* F = fold_all + (size_t)blk * fl.per_block;
+    const float* const* P = &pp.p[blk * 12];
+    float* const* Gp = &gp.p[blk * 12];
+    const float* winv = winv_all + (size_t)blk * nz * nz;
+    const double Gtot = (double)gl_total[0];
+    // ---- actnorm + 1x1 conv:  Wa = diag(e) W, ca = (b*e) W, const = 3*sum(s) + log|det W|
+    for (int k = tid; k < nz; k += 256) {
+        const double e = exp((double)(P[P_ALOGS][k] * 3.0f)), b = (double)P[P_AB][k];
+        double t1 = 0.0, t2 = 0.0;
+        for (int n = 0; n < nz; ++n) {
+            const double wkn = (double)P[P_W][k * nz + n];
+            t1 += wkn * (double)F[fl.dWa + k * nz + n];
+            t2 += wkn * (double)F[fl.dca + n];
+        }
+        if (Gp[P_AB]) Gp[P_AB][k] = (float)(e * t2);
+        if (Gp[P_ALOGS]) Gp[P_ALOGS][k] = (float)(3.0 * e * (t1 + b * t2) + 3.0 * Gtot);
+    }
+    if (Gp[P_W])
+        for (int idx = tid; idx < nz * nz; idx += 256) {
+            const int k = idx / nz, n = idx % nz;
+            const double e = exp((double)(P[P_ALOGS][k] * 3.0f)), b = (double)P[P_AB][k];
+            Gp[P_W][idx] = (float)(e * (double)F[fl.dWa + idx] + b * e * (double)F[fl.dca + n] + Gtot * (double)winv[n * nz + k]);
+        }
+    // ---- fc_1 / fc_2:  W' = W diag(e), c = b*e
+    for (int layer = 0; layer < 2; ++layer) {
+        const int iw = layer ? P_W2 : P_W1, ib = layer ? P_B2 : P_B1, il = layer ? P_LOGS2 : P_LOGS1;
+        const int rows = layer ? w : half, oW = layer ? fl.dW2 : fl.dW1, oc = layer ? fl.dc2 : fl.dc1;
+        for (int n = tid; n < w; n += 256) {
+            const double e = exp((double)(P[il][n] * 3.0f)), b = (double)P[ib][n], dc = (double)F[oc + n];
+            double u = 0.0;
+            for (int k = 0; k < rows; ++k) u += (double)P[iw][k * w + n] * (double)F[oW + k * w + n];
+            if (Gp[ib]) Gp[ib][n] = (float)(dc * e);
+            if (Gp[il]) Gp[il][n] = (float)(3.0 * e * (u + b * dc));
+        }
+        if (Gp[iw])
+            for (int idx = tid; idx < rows * w; idx += 256) {
+                const int n = idx % w;
+                Gp[iw][idx] = (float)((double)F[oW + idx] * exp((double)(P[il][n] * 3.0f)));
+            }
+    }
+    // ---- fc_zeros: column c = 2f + which (shift / pre-sigmoid interleaved, model.py:411-413)
+    for (int c = tid; c < nz; c += 256) {
+        const int f = c >> 1, which = c & 1;
+        const int oW = which ? fl.dW3p : fl.dW3s, oc = which ? fl.dc3p : fl.dc3s;
+        const double e = exp((double)(P[P_LOGS3][c] * 3.0f)), b = (double)P[P_B3][c], dc = (double)F[oc + f];
+        double u = 0.0;
+        for (int k = 0; k < w; ++k) u += (double)P[P_W3][k * nz + c] * (double)F[oW + k * half + f];
+        if (Gp[P_B3]) Gp[P_B3][c] = (float)(dc * e);
+        if (Gp[P_LOGS3]) Gp[P_LOGS3][c] = (float)(3.0 * e * (u + b * dc));
+    }
+    if (Gp[P_W3])
+        for (int idx = tid; idx < w * nz; idx += 256) {
+            const int k = idx / nz, c = idx % nz, f = c >> 1, which = c & 1;
+            const int oW = which ? fl.dW3p : fl.dW3s;
+            Gp[P_W3][idx] = (float)((double)F[oW + k * half + f] * exp((double)(P[P_LOGS3][c] * 3.0f)));
+        }
+}
+}  // namespace
+
+hipError_t lsnf_launch_backward_params(const LsnfGeo& g, const float* plan, const float* const* params_host,
+                                       float* const* grads_host, int B, const float* z_in, const float* z_out,
+                                       const float* z_saved, const float* g_z1, const float* g_logdet, int ll_mode,
+                                       float ll_scale, float* g_z_in, float* workspace, int vec4, hipStream_t stream) {
+    const LsnfFoldLayout fl = lsnf_fold_layout(g.nz, g.width);
+    float* gl_total = workspace;
+    float* fold = workspace + 4;
+    float* dump = fold + (size_t)g.depth * fl.per_block;
+    hipError_t e = hipMemsetAsync(workspace, 0, sizeof(float) * (4 + (size_t)g.depth * fl.per_block), stream);
+    if (e != hipSuccess) return e;
+    e = lsnf_launch_backward_z(g, plan, B, z_out, z_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, dump, gl_total, vec4, stream);
+    if (e != hipSuccess) return e;
+    TnArgs t;
+    t.z_in = z_in; t.z_out = z_out; t.z_saved = z_saved; t.dump = dump; t.fold = fold;
+    t.B = B; t.nz = g.nz; t.half = g.half; t.width = g.width; t.depth = g.depth;
+    t.chunk = 1024;                                  // samples per workgroup (even)
+    const unsigned chunks = (unsigned)((B + t.chunk - 1) / t.chunk);
+    hipLaunchKernelGGL(lsnf_tn_gemm_kernel, dim3(g.depth * 5, chunks), dim3(256), 0, stream, t);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    LsnfParamPtrs pp; LsnfGradPtrs gp;
+    for (int i = 0; i < LSNF_MAX_DEPTH * 12; ++i) {
+        pp.p[i] = i < g.depth * 12 ? params_host[i] : nullptr;
+        gp.p[i] = i < g.depth * 12 ? grads_host[i] : nullptr;
+    }
+    hipLaunchKernelGGL(lsnf_unfold_kernel, dim3(g.depth), dim3(256), 0, stream, pp, gp, (const float*)fold,
+                       (const float*)gl_total, plan + g.off_winv, g.nz, g.width);
+    return hipGetLastError();
+}

@@ -189,3 +189,40 @@ def backward_z(plan: FlowPlan, z_out: torch.Tensor, z_saved: Optional[torch.Tens
                                  _stream_ptr(z_out.device))
     _lib.check(rc, "lsnf_backward_z")
     return g_in
+
+
+def backward_params(plan: FlowPlan, params: Sequence[torch.Tensor], z_in: torch.Tensor, z_out: torch.Tensor,
+                    z_saved: Optional[torch.Tensor], g_z1: Optional[torch.Tensor] = None,
+                    g_logdet: Optional[torch.Tensor] = None, ll_scale: Optional[float] = None,
+                    want_grad_z: bool = False):
+    """dL/dtheta for the depth*12 live tensors (train.py:406-411).  Returns a list of gradients shaped like
+    `params` (and dL/dz_in as a second value if want_grad_z)."""
+    lib = _lib.load()
+    _need_cuda(z_in, "z_in")
+    _need_cuda(z_out, "z_out")
+    B = z_out.shape[0]
+    if len(params) != plan.depth * LSNF_PARAMS_PER_BLOCK:
+        raise LsnfError(f"expected {plan.depth * LSNF_PARAMS_PER_BLOCK} parameter tensors, got {len(params)}")
+    for name, t in (("z_saved", z_saved), ("g_z1", g_z1), ("g_logdet", g_logdet)):
+        if t is not None:
+            _need_cuda(t, name)
+    raw = []
+    for i, p in enumerate(params):
+        t = p.detach()
+        _need_cuda(t, f"param[{i}]")
+        raw.append(t)
+    grads = [torch.empty_like(t) for t in raw]
+    g_in = torch.empty_like(z_out) if want_grad_z else None
+    nws = lib.lsnf_backward_params_workspace_floats(plan.nz, plan.width, plan.depth, B)
+    ws = torch.empty(nws, dtype=torch.float32, device=z_out.device)
+    parr = (ctypes.c_void_p * len(raw))(*[t.data_ptr() for t in raw])
+    garr = (ctypes.c_void_p * len(grads))(*[t.data_ptr() for t in grads])
+    with torch.cuda.device(z_out.device):
+        rc = lib.lsnf_backward_params(_ptr(plan.buf), parr, garr, plan.nz, plan.width, plan.depth, plan.coupling, B,
+                                      _ptr(z_in), _ptr(z_out), _ptr(z_saved), _ptr(g_z1), _ptr(g_logdet),
+                                      0 if ll_scale is None else 1, float(ll_scale or 0.0), _ptr(g_in), _ptr(ws),
+                                      _stream_ptr(z_out.device))
+    _lib.check(rc, "lsnf_backward_params")
+    if want_grad_z:
+        return grads, g_in
+    return grads

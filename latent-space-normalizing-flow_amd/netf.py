@@ -1,0 +1,249 @@
+"""`_netF`: drop-in replacement for the reference's flow prior (reference model.py:460-498).
+
+Same constructor (`_netF(hps, nz)`), same `forward` signature and return conventions, the same
+85-key `state_dict` (so reference checkpoints load unchanged, train.py:343-348), the same initial
+distributions drawn in the same RNG order -- but every number is produced by the HIP kernels of
+liblsnf_flow.so.  The sub-modules below only hold parameters under the reference's names; the
+compute path is a single `torch.autograd.Function` around the fused stack kernels.
+
+There is no CPU path: calling the module on CPU tensors raises `LsnfError`.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import flow
+from ._lib import LsnfError
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter holders (names / shapes / init mirror reference model.py:171-177, 227-233, 312-319,
+# 334-342, 296-303, 367-387, 352-356)
+# ---------------------------------------------------------------------------------------------
+class actnorm(nn.Module):
+    def __init__(self, nz):
+        super().__init__()
+        self.b = nn.Parameter(torch.randn(1, nz) * 0.05)
+        self.register_parameter(name="bias", param=self.b)      # the reference's duplicate key (model.py:231)
+        self.logs = nn.Parameter(torch.randn(1, nz) * 0.05)
+
+
+class invertible_1x1_conv(nn.Module):
+    def __init__(self, width, nz):
+        super().__init__()
+        w_init = np.linalg.qr(np.random.randn(nz, nz))[0].astype("float32")   # random orthogonal (model.py:176)
+        self.w = nn.Parameter(torch.tensor(w_init, dtype=torch.float))
+
+
+class fc(nn.Module):
+    def __init__(self, n_in, width):
+        super().__init__()
+        self.width = width
+        self.actnorm = actnorm(nz=width)
+        self.w = nn.Parameter(torch.randn(n_in, width) * 0.05)
+        self.b = nn.Parameter(torch.zeros(1, width))            # unused by the reference's forward (model.py:327-330)
+
+
+class fc_zeros(nn.Module):
+    def __init__(self, n_in, width):
+        super().__init__()
+        self.width = width
+        self.w = nn.Parameter(torch.zeros(n_in, width))
+        self.b = nn.Parameter(torch.zeros(1, width))
+        self.logs = nn.Parameter(torch.zeros(1, width))
+
+
+class f(nn.Module):
+    def __init__(self, width, n_in=None, n_out=None):
+        super().__init__()
+        self.n_out = n_out
+        self.fc_1 = fc(n_in, width)
+        self.fc_2 = fc(width, width)
+        self.fc_zeros = fc_zeros(width, n_out)
+
+
+class revnet2d_step(nn.Module):
+    def __init__(self, id, hps, nz):
+        super().__init__()
+        self.actnorm = actnorm(nz=nz)
+        if hps.f_flow_permutation == 2:
+            self.invertible_1x1_conv = invertible_1x1_conv(hps.f_width, nz=nz)
+            self.shuffle_features = None
+        else:
+            # the reference's permutations 0 and 1 do not run; only the 1x1 conv exists here
+            raise Exception("only f_flow_permutation == 2 (invertible 1x1 conv) is supported")
+        self.id = id
+        assert nz % 2 == 0
+        if hps.f_flow_coupling == 1:
+            self.f = f(hps.f_width, nz // 2, nz)
+        elif hps.f_flow_coupling == 0:
+            raise NotImplementedError("additive coupling (f_flow_coupling=0) has no HIP kernel yet; the reference "
+                                      "default and every published config use the affine coupling (=1)")
+        else:
+            raise Exception()
+
+    def live_parameters(self) -> List[nn.Parameter]:
+        """The 12 tensors that reach the kernels, in the ABI's order (include/lsnf_flow.h)."""
+        ff = self.f
+        return [self.actnorm.b, self.actnorm.logs, self.invertible_1x1_conv.w,
+                ff.fc_1.w, ff.fc_1.actnorm.b, ff.fc_1.actnorm.logs,
+                ff.fc_2.w, ff.fc_2.actnorm.b, ff.fc_2.actnorm.logs,
+                ff.fc_zeros.w, ff.fc_zeros.b, ff.fc_zeros.logs]
+
+
+class revnet2d(nn.Module):
+    def __init__(self, hps, nz):
+        super().__init__()
+        self.hps = hps
+        self.revnet2d_step_s = nn.ModuleList([revnet2d_step(str(i), hps, nz=nz) for i in range(hps.f_depth)])
+
+
+# ---------------------------------------------------------------------------------------------
+# autograd bridge
+# ---------------------------------------------------------------------------------------------
+class _Upstream:
+    """Hand-over between the two autograd nodes below (filled by _FlowStackFn.backward)."""
+    __slots__ = ("g_z1", "g_logdet", "z", "z1", "saved", "plan_key")
+
+    def __init__(self):
+        self.g_z1 = self.g_logdet = self.z = self.z1 = self.saved = self.plan_key = None
+
+
+class _ParamGate(torch.autograd.Function):
+    """(*live_params) -> scalar token.  Exists so that parameter gradients are computed ONLY when the
+    autograd engine actually needs them: `torch.autograd.grad(f, z)` in the Langevin loop (train.py:323)
+    never executes this node's backward, `loss_f.backward()` (train.py:411) does."""
+
+    @staticmethod
+    def forward(ctx, module, holder, *params):
+        ctx.module, ctx.holder, ctx.n = module, holder, len(params)
+        return params[0].new_zeros(())
+
+    @staticmethod
+    def backward(ctx, _g_token):
+        h, module = ctx.holder, ctx.module
+        if h.z1 is None:
+            raise LsnfError("parameter gradients requested before the flow's backward ran")
+        if module._plan_key != h.plan_key:
+            raise LsnfError("flow parameters were modified between forward and backward")
+        grads = flow.backward_params(module._plan(), module._param_list(), h.z, h.z1, h.saved, h.g_z1, h.g_logdet)
+        grads = [g if need else None for g, need in zip(grads, ctx.needs_input_grad[2:])]
+        return (None, None, *grads)
+
+
+class _FlowStackFn(torch.autograd.Function):
+    """(z, objective, token) -> (z1, logdet).  Forward: lsnf_forward (block outputs kept for the backward);
+    backward: lsnf_backward_z for z; the upstream gradients are handed to _ParamGate for the parameters."""
+
+    @staticmethod
+    def forward(ctx, module, holder, z, objective, token):
+        plan = module._plan()
+        z1, logdet, _, saved = flow.forward(plan, z, objective, want_ll=False, save_for_backward=True)
+        ctx.module, ctx.holder = module, holder
+        ctx.plan_key = module._plan_key
+        ctx.save_for_backward(z, z1, saved if saved is not None else z1.new_empty(0))
+        return z1, logdet
+
+    @staticmethod
+    def backward(ctx, g_z1, g_logdet):
+        module, h = ctx.module, ctx.holder
+        z, z1, saved = ctx.saved_tensors
+        if module._plan_key != ctx.plan_key:
+            raise LsnfError("flow parameters were modified between forward and backward")
+        saved_t = saved if saved.numel() else None
+        g_z1 = None if g_z1 is None else g_z1.contiguous()
+        g_logdet = None if g_logdet is None else g_logdet.contiguous()
+        g_z = flow.backward_z(module._plan(), z1, saved_t, g_z1, g_logdet) if ctx.needs_input_grad[2] else None
+        g_obj = g_logdet if ctx.needs_input_grad[3] else None
+        g_tok = None
+        if ctx.needs_input_grad[4]:
+            h.g_z1, h.g_logdet, h.z, h.z1, h.saved, h.plan_key = g_z1, g_logdet, z, z1, saved_t, ctx.plan_key
+            g_tok = z1.new_zeros(())
+        return None, None, g_z, g_obj, g_tok
+
+
+class _netF(nn.Module):
+    """Reference model.py:460-498.  `hps` needs f_n_levels, f_depth, f_flow_permutation, f_width,
+    f_flow_coupling (model.py:355-356,372-387,465)."""
+
+    def __init__(self, hps, nz, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        revnet2d_s = []
+        self.hps = hps
+        self.nz = nz
+        for i in range(hps.f_n_levels):
+            revnet2d_s.append(revnet2d(hps, nz=nz))
+            if i < hps.f_n_levels - 1:
+                raise NotImplementedError      # as the reference (model.py:467-470): no split layer
+        self.revnet2d_s = nn.ModuleList(revnet2d_s)
+        self._cached_plan: Optional[flow.FlowPlan] = None
+        self._plan_key = None
+
+    # ---- prepared weights, re-derived only when a parameter changed -------------------------------
+    def _param_list(self) -> List[nn.Parameter]:
+        out: List[nn.Parameter] = []
+        for step in self.revnet2d_s[0].revnet2d_step_s:
+            out += step.live_parameters()
+        return out
+
+    def _plan(self) -> flow.FlowPlan:
+        params = self._param_list()
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._cached_plan is None or key != self._plan_key or self._cached_plan.device != params[0].device:
+            for p in params:
+                if not p.is_cuda:
+                    raise LsnfError("_netF lives on %s: move it to the GPU (netF.to(device)); there is no CPU path"
+                                    % p.device)
+            reuse = self._cached_plan if (self._cached_plan is not None and
+                                          self._cached_plan.device == params[0].device) else None
+            with torch.no_grad():
+                tensors = [p.detach().contiguous() for p in params]
+                self._cached_plan = flow.prepare(tensors, self.nz, self.hps.f_width, self.hps.f_depth,
+                                                 self.hps.f_flow_coupling, plan=reuse)
+            self._plan_key = key
+        return self._cached_plan
+
+    # ---- reference forward signature (model.py:473) ---------------------------------------------
+    def forward(self, z, objective, init=False, reverse=False, eps=None, eps_std=None, z2_s=None, return_obj=False):
+        if init:
+            raise NotImplementedError("data-dependent actnorm init (init=True) is never used by the reference's "
+                                      "train.py (all call sites pass init=False) and is not implemented")
+        if z.dim() != 2:
+            raise ValueError(f"z must be (B, nz); got shape {tuple(z.shape)} (note: the reference's "
+                             f"torch.squeeze(z) call site breaks for B == 1, train.py:316)")
+        z = z.contiguous()
+        objective = objective.contiguous()
+        if not reverse:
+            params = self._param_list()
+            if torch.is_grad_enabled() and (z.requires_grad or objective.requires_grad or
+                                            any(p.requires_grad for p in params)):
+                holder = _Upstream()
+                token = _ParamGate.apply(self, holder, *params)
+                z1, logdet = _FlowStackFn.apply(self, holder, z, objective, token)
+            else:
+                z1, logdet, _, _ = flow.forward(self._plan(), z.detach(), objective.detach(), want_ll=False)
+            return z1, logdet, []
+        if torch.is_grad_enabled() and z.requires_grad:
+            raise NotImplementedError("reverse pass is inference-only (the reference calls it under no_grad, "
+                                      "train.py:433-434,473-475,569-571)")
+        x, obj = flow.reverse(self._plan(), z.detach(), objective.detach())
+        if not return_obj:
+            return x
+        return x, -obj
+
+    # ---- fused extras (not in the reference; train.py:316-323 collapsed into two launches) ---------
+    def log_prob(self, z):
+        """(z1, logdet, ll) with ll = -0.5*sum z1^2 + log(2*pi) + logdet (train.py:317-319), one launch."""
+        z1, logdet, ll, _ = flow.forward(self._plan(), z.detach().contiguous(), None, want_ll=True)
+        return z1, logdet, ll
+
+    def log_prob_and_grad(self, z, scale=-1.0):
+        """ll and d(scale * sum ll)/dz (train.py:320-323 uses scale = -1), two launches."""
+        plan = self._plan()
+        z1, logdet, ll, saved = flow.forward(plan, z.detach().contiguous(), None, want_ll=True, save_for_backward=True)
+        g = flow.backward_z(plan, z1, saved, ll_scale=scale)
+        return ll, g

@@ -1,0 +1,102 @@
+"""CPU: the drop-in boundary -- `_netF` module surface (constructor, state_dict contract, init parity,
+loud failure without a GPU) and the C ABI (library loads, exports every symbol the header declares)."""
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from oracle import flow_oracle as O
+
+import lsnf_amd
+
+
+def hps(width=64, depth=5, levels=1, perm=2, coupling=1):
+    return types.SimpleNamespace(f_n_levels=levels, f_depth=depth, f_flow_permutation=perm, f_width=width,
+                                 f_flow_coupling=coupling)
+
+
+def test_state_dict_contract_matches_reference():
+    net = lsnf_amd._netF(hps(64), nz=100)
+    sd = net.state_dict()
+    assert list(sd.keys()) == O.state_dict_keys(5)          # same keys, same registration order
+    assert len(list(net.named_parameters())) == 70           # 85 keys, 70 named parameters (aliases de-duplicated)
+    p, _ = load_golden("c1_nz100_w64_B256")
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(p[k].shape), k
+    net.load_state_dict(p, strict=True)                      # a reference-keyed checkpoint loads unchanged
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, p[k])
+    pre = O.block_prefix(0)
+    assert net.state_dict()[pre + "actnorm.b"].data_ptr() == net.state_dict()[pre + "actnorm.bias"].data_ptr()
+
+
+@pytest.mark.parametrize("name,nz,width,seed", [("c1_nz100_w64_B256", 100, 64, 1), ("c5_nz100_w128_B100", 100, 128, 3),
+                                                ("tiny_nz8_w4_B7", 8, 4, 11)])
+def test_init_is_bitwise_the_reference_init(name, nz, width, seed):
+    """Same distributions drawn in the same RNG order as reference model.py:176,230-233,318-319,340-342: under the
+    same seeds the parameters equal the reference's (fc_zeros excluded: the fixtures perturb those)."""
+    p, _ = load_golden(name)
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    net = lsnf_amd._netF(hps(width), nz=nz)
+    for k, v in net.state_dict().items():
+        if ".fc_zeros." in k:
+            assert torch.count_nonzero(v) == 0
+        else:
+            assert torch.equal(v, p[k]), k
+
+
+def test_constructor_errors_mirror_reference():
+    with pytest.raises(NotImplementedError):
+        lsnf_amd._netF(hps(levels=2), nz=8)                   # model.py:467-470
+    with pytest.raises(Exception):
+        lsnf_amd._netF(hps(perm=0), nz=8)                     # model.py:378-379
+    with pytest.raises(NotImplementedError):
+        lsnf_amd._netF(hps(coupling=0), nz=8)
+
+
+def test_cpu_call_fails_loudly_no_fallback():
+    net = lsnf_amd._netF(hps(4), nz=8)
+    with pytest.raises(lsnf_amd.LsnfError):
+        net(torch.zeros(3, 8), objective=torch.zeros(3))
+    with pytest.raises(lsnf_amd.LsnfError):
+        net(torch.zeros(3, 8), objective=torch.zeros(3), reverse=True)
+    with pytest.raises(NotImplementedError):
+        net(torch.zeros(3, 8), objective=torch.zeros(3), init=True)
+    with pytest.raises(ValueError):
+        net(torch.zeros(8), objective=torch.zeros(1))          # the B == 1 squeeze quirk (train.py:316)
+
+
+def test_module_protocol_used_by_train_py():
+    net = lsnf_amd._netF(hps(4), nz=8)
+    net.apply(lambda m: None)                                  # train.py:272
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)          # train.py:295 (no duplicate-parameter complaint)
+    assert len(opt.param_groups[0]["params"]) == 70
+    net.train(); net.eval()
+    assert "revnet2d_step_s" in repr(net)
+    live = net._param_list()
+    assert len(live) == 60 and all(isinstance(t, torch.nn.Parameter) for t in live)
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "lsnf_flow.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(lsnf_[a-z_0-9]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    lib = lsnf_amd.load_library()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/lsnf_flow.h but not exported"
+    assert sorted(lsnf_amd.exported_symbols()) == declared      # the ctypes table covers the whole header
+    assert lib.lsnf_abi_version() == 1
+
+
+def test_geometry_queries_need_no_gpu():
+    lib = lsnf_amd.load_library()
+    assert lib.lsnf_plan_floats(128, 64, 5, 1) > 5 * 32768
+    assert lib.lsnf_plan_floats(130, 64, 5, 1) == 0 and lib.lsnf_plan_floats(7, 4, 5, 1) == 0
+    assert lib.lsnf_plan_floats(128, 64, 17, 1) == 0
+    assert lib.lsnf_backward_params_workspace_floats(128, 64, 5, 100) > 0
