@@ -108,13 +108,11 @@ def main():
     z1 = torch.empty_like(z)
     logdet = torch.empty(B_PER_GPU, device=dev)
     ll = torch.empty(B_PER_GPU, device=dev)
-    total = torch.zeros(1, device=dev)
+    from lsnf_amd import parallel
 
     def step():
         lsnf_amd.forward(plan, z, out=(z1, logdet, ll))
-        torch.sum(ll, dim=0, keepdim=True, out=total)
-        if dist is not None:
-            dist.all_reduce(total)      # the single collective of the path: sum of log-prob over ranks
+        return parallel.reduce_sum_ll(ll)   # on-device sum (train.py:320) + the single all-reduce when N > 1
 
     def fence():
         if dist is not None:

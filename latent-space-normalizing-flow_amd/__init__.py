@@ -4,7 +4,7 @@
 
 The compute path is liblsnf_flow.so (hand-written HIP, gfx950); see include/lsnf_flow.h."""
 from ._lib import LsnfError, LIB_PATH, exported_symbols, load as load_library  # noqa: F401
-from . import flow  # noqa: F401
+from . import flow, parallel  # noqa: F401
 from .flow import FlowPlan, prepare, forward, reverse, backward_z, backward_params, params_from_state_dict  # noqa: F401
 from .netf import _netF  # noqa: F401
 

@@ -9,7 +9,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblsnf_flow.so")
+# LSNF_LIB_PATH: developer override to A/B alternative BUILDS of the same library (tools/); not a fallback.
+LIB_PATH = os.environ.get("LSNF_LIB_PATH") or os.path.join(_HERE, "liblsnf_flow.so")
 
 LSNF_PARAMS_PER_BLOCK = 12
 ABI_VERSION = 1

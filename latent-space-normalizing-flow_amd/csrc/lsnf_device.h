@@ -36,23 +36,40 @@ __device__ __forceinline__ void lsnf_issue_panel(const float* __restrict__ gsrc,
 // reading the panel that was consumed before.
 __device__ __forceinline__ void lsnf_panel_barrier() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef LSNF_ABLATE_BARRIER   // timing diagnostic only (racy): prices the per-panel workgroup barrier
     __syncthreads();
+#endif
 }
 
 // ---- one panel of MFMAs: acc(32 features x 32 samples) += W_panel^T * in ----------------------
 // lbuf: panel in LDS (fragment order), in[kt]: activations tile kt (B operand), acc: C/D.
+// Software-pipelined per k-tile: the four ds_read_b128 of k-tile kt+1 are issued BEFORE the 16 MFMAs of
+// k-tile kt (two sets of fragment registers), so that hipcc's lgkmcnt(0) before the next tile's first
+// MFMA finds the reads long complete.  The sched_group_barriers pin that order (left alone hipcc emits
+// read -> lgkmcnt(0) -> 4 MFMA, fully serialised: measured 27 % slower).
 template <int KT>
 __device__ __forceinline__ void lsnf_panel_mma(f32x16& acc, const f32x16* in, const float* lbuf, int lane) {
+    const f32x4* wp = reinterpret_cast<const f32x4*>(lbuf) + lane;
+    __builtin_amdgcn_sched_barrier(0);                       // nothing from before drifts into the pipeline
+    f32x4 w0 = wp[0], w1 = wp[64], w2 = wp[128], w3 = wp[192];
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);       // k-tile 0: its four fragment reads
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(lbuf + ((kt * 4 + g) * 64 + lane) * 4);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], in[kt][4 * g + 0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], in[kt][4 * g + 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], in[kt][4 * g + 2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], in[kt][4 * g + 3], acc, 0, 0, 0);
+        f32x4 n0 = w0, n1 = w1, n2 = w2, n3 = w3;
+        if (kt + 1 < KT) {                                   // whole next k-tile in flight under 16 MFMAs
+            n0 = wp[((kt + 1) * 4 + 0) * 64]; n1 = wp[((kt + 1) * 4 + 1) * 64];
+            n2 = wp[((kt + 1) * 4 + 2) * 64]; n3 = wp[((kt + 1) * 4 + 3) * 64];
         }
+#define LSNF_MFMA4(W, G)                                                                      \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W[0], in[kt][4 * G + 0], acc, 0, 0, 0);    \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W[1], in[kt][4 * G + 1], acc, 0, 0, 0);    \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W[2], in[kt][4 * G + 2], acc, 0, 0, 0);    \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W[3], in[kt][4 * G + 3], acc, 0, 0, 0);
+        LSNF_MFMA4(w0, 0) LSNF_MFMA4(w1, 1) LSNF_MFMA4(w2, 2) LSNF_MFMA4(w3, 3)
+#undef LSNF_MFMA4
+        if (kt + 1 < KT) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // 4 DS reads (prefetch) first
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                   // then this k-tile's 16 MFMA
+        w0 = n0; w1 = n1; w2 = n2; w3 = n3;
     }
 }
 
@@ -85,17 +102,24 @@ __device__ __forceinline__ f32x16 lsnf_relu16(f32x16 a) {
 //   reference: scale = sigmoid(h[:,1::2] + 2) (model.py:413; the +2 is folded into the bias),
 //              log(scale) (model.py:418)
 __device__ __forceinline__ void lsnf_sigmoid_logsig(float p, float& sig, float& lsig) {
+#ifdef LSNF_ABLATE_EPILOGUE   // timing diagnostic only (wrong numbers): prices the transcendental epilogue
+    sig = p * 0.25f + 0.5f; lsig = p; return;
+#endif
     const float a = fabsf(p);
-#ifdef LSNF_FAST_MATH
-    const float e = __expf(-a);
-    const float d = 1.0f + e;
-    const float r = __fdividef(1.0f, d);
-    const float dm1 = d - 1.0f;
-    const float l = (dm1 == 0.0f) ? e : __logf(d) * __fdividef(e, dm1);   // log1p(e)
-#else
-    const float e = expf(-a);           // in (0, 1]
+#ifdef LSNF_OCML_MATH               // reference build of the epilogue on OCML expf/log1pf (slow, ~110 VALU/element)
+    const float e = expf(-a);
     const float r = 1.0f / (1.0f + e);
     const float l = log1pf(e);
+#else
+    // Hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32: <= 1 ulp each), ~20 VALU/element.
+    //   e = exp(-a) in (0,1];  d = 1+e in [1,2];  dm1 = d-1 is exact;  log1p(e) = log(d) * e/dm1
+    // (the classic correction for the rounding of 1+e), and = e when 1+e rounds to 1.
+    const float e = __builtin_amdgcn_exp2f(a * -1.4426950408889634f);
+    const float d = 1.0f + e;
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float dm1 = d - 1.0f;
+    const float lg = __builtin_amdgcn_logf(d) * 0.6931471805599453f;
+    const float l = (dm1 == 0.0f) ? e : lg * (e * __builtin_amdgcn_rcpf(dm1));
 #endif
     sig = (p >= 0.0f) ? r : e * r;
     lsig = fminf(p, 0.0f) - l;

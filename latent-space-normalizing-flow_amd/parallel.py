@@ -1,0 +1,102 @@
+"""Data-parallel evaluation of the flow prior: one process per GPU, rows of z sharded, weights replicated.
+
+The per-sample flow evaluation needs no communication (every op of reference model.py:389-422 is
+row-independent).  The only exchange is ONE all-reduce (sum) of a 3-float vector per evaluation:
+[sum_b ll, sum_b logdet, row count] -- RCCL over xGMI on GPUs (`backend="nccl"` is RCCL on ROCm), gloo on
+CPU in the tests.  For training steps the flow's parameter gradients (<= 0.94 MB) travel as ONE flat bucket.
+
+The reference itself has no distributed code: this module adds what north_star asks for.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(device: Optional[torch.device] = None, backend: Optional[str] = None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run sets them).
+    Returns (rank, world, local_rank).  No-op for WORLD_SIZE == 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if (device is not None and device.type == "cuda") else "gloo"
+        kw = {"device_id": device} if backend == "nccl" and device is not None else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, local_rank
+
+
+def shard_bounds(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous slab [start, stop) of `n_rows` owned by `rank`; slab sizes differ by at most one row."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    base, rem = divmod(n_rows, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def reduce_log_prob_stats(ll: torch.Tensor, logdet: torch.Tensor, group=None) -> torch.Tensor:
+    """The single collective of the path.  Returns a float64 tensor [sum ll, sum logdet, rows] over ALL ranks.
+    (float64 so that the reduced loss does not depend on the number of ranks beyond fp32 rounding of the
+    per-rank partial sums.)"""
+    stats = torch.stack([ll.sum(dtype=torch.float64), logdet.sum(dtype=torch.float64),
+                         torch.tensor(float(ll.numel()), dtype=torch.float64, device=ll.device)])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+    return stats
+
+
+def reduce_sum_ll(ll: torch.Tensor, group=None) -> torch.Tensor:
+    """Lean form of the collective for the hot loop (train.py:320 only needs sum ll): one on-device
+    reduction + one all-reduce of a single float64.  Returns a 1-element float64 tensor."""
+    s = ll.sum(dtype=torch.float64).reshape(1)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+    return s
+
+
+def sharded_log_prob(evaluate: Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]],
+                     z_local: torch.Tensor, group=None):
+    """evaluate(z_local) -> (z1, logdet, ll) on this rank's rows (product: `_netF.log_prob`).
+    Returns (z1, logdet, ll, stats) with stats = [global sum ll, global sum logdet, global rows]."""
+    z1, logdet, ll = evaluate(z_local)
+    return z1, logdet, ll, reduce_log_prob_stats(ll, logdet, group)
+
+
+def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, average: bool = True) -> int:
+    """Sum (or average) the .grad of the given parameters over all ranks as ONE flat bucket (the flow has
+    <= 233 760 fp32 parameters = 0.94 MB, below any sensible bucket size).  Parameters whose grad is None
+    on every rank (fc_1.b, fc_2.b) are skipped.  Returns the number of elements reduced."""
+    ps = [p for p in params if p.grad is not None]
+    if not ps:
+        return 0
+    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            flat /= dist.get_world_size(group)
+    o = 0
+    for p in ps:
+        n = p.grad.numel()
+        p.grad.copy_(flat[o:o + n].view_as(p.grad))
+        o += n
+    return o
+
+
+def broadcast_parameters(params: Iterable[torch.Tensor], src: int = 0, group=None) -> None:
+    """Replicate the flow weights from `src` to every rank (once, before the first step)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    ps = list(params)
+    flat = torch.cat([p.detach().reshape(-1) for p in ps])
+    dist.broadcast(flat, src=src, group=group)
+    o = 0
+    with torch.no_grad():
+        for p in ps:
+            n = p.numel()
+            p.copy_(flat[o:o + n].view_as(p))
+            o += n

@@ -1,0 +1,100 @@
+"""CPU, world_size 2, gloo: the N > 1 path of the flow evaluation -- row sharding, the single all-reduce of
+[sum ll, sum logdet, rows], one-bucket gradient all-reduce, parameter broadcast.  The per-shard evaluator
+is the oracle here (tests may use it); on GPUs it is `_netF.log_prob` and the backend is RCCL."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import flow_oracle as O
+import lsnf_amd
+from lsnf_amd import parallel as P
+
+NZ, WIDTH, DEPTH, B = 20, 12, 3, 37
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    r, w, _ = P.init_from_env(torch.device("cpu"))
+    assert (r, w) == (rank, world)
+    p = O.init_params(NZ, WIDTH, DEPTH, seed=4)
+    z = torch.randn(B, NZ, generator=torch.Generator().manual_seed(5))
+    lo, hi = P.shard_bounds(B, world, rank)
+    # (1) sharded log-prob + the one collective
+    z1, ld, ll, stats = P.sharded_log_prob(lambda t: O.flow_log_prob(p, t), z[lo:hi])
+    # (2) broadcast: rank 1 starts from different weights and must end up with rank 0's
+    q = O.init_params(NZ, WIDTH, DEPTH, seed=4 + rank)
+    live = [q[k] for k in sorted(q) if O.is_live_param(k)]
+    P.broadcast_parameters(live, src=0)
+    same = all(torch.equal(q[k], p[k]) for k in sorted(q) if O.is_live_param(k))
+    # (3) gradient bucket: local loss = -sum(ll_local)/B_global  -> summed grads == full-batch -mean(ll) grads
+    keys = sorted(k for k in p if O.is_live_param(k))
+    leaves = [torch.nn.Parameter(p[k].clone()) for k in keys]
+    pp = dict(p); pp.update(dict(zip(keys, leaves)))
+    _, _, ll_l = O.flow_log_prob(pp, z[lo:hi])
+    (-ll_l.sum() / B).backward()
+    dead = torch.nn.Parameter(torch.zeros(3))            # a parameter without grad must be skipped
+    n = P.allreduce_gradients(leaves + [dead], average=False)
+    if rank == 0:
+        out.put({"stats": stats.tolist(), "same": same, "n": n, "ll": ll.tolist(), "lo_hi": (lo, hi),
+                 "grads": {k: l.grad.numpy().copy() for k, l in zip(keys, leaves)}})
+    else:
+        out.put({"same": same, "lo_hi": (lo, hi)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_bounds_cover_and_balance():
+    for n in (0, 1, 7, 64, 65536, 65537):
+        for w in (1, 2, 3, 8):
+            b = [P.shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        P.shard_bounds(10, 2, 2)
+
+
+def test_single_process_is_a_noop():
+    ll = torch.arange(5.0)
+    st = P.reduce_log_prob_stats(ll, 2 * ll)
+    assert st.tolist() == [10.0, 20.0, 5.0]
+
+
+def test_two_rank_gloo_matches_full_batch():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = [out.get(timeout=180) for _ in range(2)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    r0 = next(r for r in res if "stats" in r)
+    assert all(r["same"] for r in res)
+    p = O.init_params(NZ, WIDTH, DEPTH, seed=4)
+    z = torch.randn(B, NZ, generator=torch.Generator().manual_seed(5))
+    z1, ld, ll = O.flow_log_prob(p, z)
+    assert abs(r0["stats"][0] - ll.double().sum().item()) <= 1e-6 * abs(ll.double().sum().item())
+    assert abs(r0["stats"][1] - ld.double().sum().item()) <= 1e-6 * abs(ld.double().sum().item())
+    assert r0["stats"][2] == B
+    lo, hi = r0["lo_hi"]
+    assert torch.allclose(torch.tensor(r0["ll"]), ll[lo:hi], rtol=1e-6, atol=1e-5)
+    ref = O.grad_neg_mean_ll_wrt_params(p, z)
+    assert r0["n"] == sum(v.numel() for v in ref.values())
+    for k, v in ref.items():
+        assert (torch.from_numpy(r0["grads"][k]) - v).norm().item() <= 1e-5 * max(v.norm().item(), 1e-3), k
