@@ -73,8 +73,16 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_fwd_kernel(const FwdA
     const long row = live ? sample : (long)a.B - 1;
 
     f32x16 x[NZT];
+#ifdef LSNF_ABLATE_IO    // timing diagnostic only: no HBM reads of z (prices the exposed prologue load)
+#pragma unroll
+    for (int t = 0; t < NZT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[t][r] = 0.001f * (float)(lane + r + t);
+    float ell = 0.0f;
+#else
     lsnf_load_rows<HT>(x, a.z_in, row, a.nz, a.half, h, a.vec4 != 0);
     float ell = a.objective ? a.objective[row] : 0.0f;
+#endif
 
     for (int blk = 0; blk < a.n_blocks; ++blk) {
         const float* cb = cst + blk * C::CONST_FLOATS;
@@ -154,6 +162,9 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_fwd_kernel(const FwdA
 #pragma unroll
         for (int r = 0; r < 16; ++r) ss += x[t][r] * x[t][r];
     ss = lsnf_pair_sum(ss);
+#ifdef LSNF_ABLATE_IO
+    if (ss != 123.456f) return;   // keeps the computation alive, stores (practically) never happen
+#endif
     if (live) {
         lsnf_store_rows<HT>(x, a.z_out, sample, a.nz, a.half, h, a.vec4 != 0);
         if (h == 0) {

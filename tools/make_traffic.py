@@ -1,0 +1,17 @@
+"""Turn the PMC passes of tools/pmc_fwd.sh into profiles/traffic.json (read by bench.py).
+HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KB counters; gfx950 correction of
+MI355X_MICROARCH.md 'HBM': FETCH_SIZE reports half the bytes of a wide coalesced read)."""
+import csv, glob, json, sys, os
+root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
+def mean(counter, p):
+    f = glob.glob(os.path.join(root, p, "*", "*_counter_collection.csv"))[0]
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and "lsnf_fwd" in r["Kernel_Name"]]
+    return sum(v) / len(v)
+fetch_kb, write_kb = mean("FETCH_SIZE", "p3"), mean("WRITE_SIZE", "p4")
+out = {"kernel": "lsnf_fwd_kernel<FwdCfg<2,2>>", "workload": "nz=128 w=64 depth=5 B=65536",
+       "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
+       "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024,
+       "algorithmic_bytes_per_launch": 1032 * 65536,
+       "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; read side doubled (gfx950 correction)"}
+json.dump(out, open("profiles/traffic.json", "w"), indent=1)
+print(out)
