@@ -8,6 +8,11 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef LSNF_STAGGER_MODE_DEFAULT
+#define LSNF_STAGGER_MODE_DEFAULT 0
+#define LSNF_STAGGER_COUNT_DEFAULT 0
+#endif
+#include <stdio.h>
 #define LSNF_WG_THREADS 256          // 4 waves, one per SIMD; 2 workgroups co-resident per CU
 #define LSNF_WG_WAVES 4
 #define LSNF_WG_SAMPLES (LSNF_WG_WAVES * 32)
@@ -17,6 +22,37 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // feature offset inside a 32-tile of accumulator register r on lane-half h
 __device__ __forceinline__ constexpr int lsnf_feat(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---- start-up stagger of the two workgroups that share a CU ------------------------------------------
+// The two waves on a SIMD (one from each co-resident workgroup) run the same program; in lockstep they hit
+// their MFMA-free phases (prologue loads, panel starts, sigmoid/log epilogue, stores) together and the
+// matrix pipe idles.  Delaying one of them once at start-up makes those phases complementary
+// (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  Speed only, never correctness.
+//   mode 0: off; 1: waves in an odd hardware wave slot (HW_ID.wave_id & 1); 2: odd blockIdx; 3: upper half of the grid
+__device__ __forceinline__ void lsnf_stagger(int mode, int count) {
+    if (mode == 0) return;
+    bool late;
+    if (mode == 1) late = (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1) != 0;   // HW_REG_HW_ID[3:0] = wave slot
+    else if (mode == 2) late = (blockIdx.x & 1) != 0;
+    else late = blockIdx.x >= (gridDim.x >> 1);
+    if (__builtin_amdgcn_readfirstlane(late ? 1 : 0))
+        for (int i = 0; i < count; ++i) __builtin_amdgcn_s_sleep(16);             // ~1024 cycles each
+}
+#ifndef __HIP_DEVICE_COMPILE__
+#include <stdlib.h>
+// LSNF_STAGGER="mode,count" overrides the built-in default (tuning knob).
+static inline void lsnf_stagger_config(int* mode, int* count) {
+    static int m = -1, c = 0;
+    if (m < 0) {
+        m = LSNF_STAGGER_MODE_DEFAULT; c = LSNF_STAGGER_COUNT_DEFAULT;
+        const char* e = getenv("LSNF_STAGGER");
+        if (e) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2) { m = a; c = b; } }
+    }
+    *mode = m; *count = c;
+}
+#else
+static inline void lsnf_stagger_config(int*, int*) {}
+#endif
 
 // ---- LDS-DMA of one weight panel (KT KiB*4) by the 4 waves of the workgroup -------------------
 // Each wave-instruction moves 1 KiB (64 lanes x 16 B), destination = wave-uniform base + lane*16.
@@ -211,6 +247,71 @@ __device__ __forceinline__ void lsnf_static_for(F&& f) {
         lsnf_static_for<N, F, I + 1>(static_cast<F&&>(f));
     }
 }
+
+// ---- two n-tiles at once: two independent accumulator chains sharing the B operand ---------------------
+// lbuf holds tile 0's KT k-tiles followed by tile 1's (two consecutive panels of the packed stream).
+// Per half k-tile: 4 ds_read_b128 (2 fragment groups x 2 tiles) are prefetched under the previous 16 MFMAs.
+template <int KT>
+__device__ __forceinline__ void lsnf_panel_mma2(f32x16& acc0, f32x16& acc1, const f32x16* in, const float* lbuf, int lane) {
+    const f32x4* wp = reinterpret_cast<const f32x4*>(lbuf) + lane;
+    constexpr int T1 = KT * 4 * 64;                          // f32x4 offset of tile 1's panel
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 a0 = wp[0], a1 = wp[64], b0 = wp[T1], b1 = wp[T1 + 64];
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int H = 0; H < 2 * KT; ++H) {                       // half k-tiles: groups 2H, 2H+1
+        const int kt = H >> 1, g0 = (H & 1) * 2;
+        f32x4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+        if (H + 1 < 2 * KT) {
+            na0 = wp[(2 * H + 2) * 64]; na1 = wp[(2 * H + 3) * 64];
+            nb0 = wp[T1 + (2 * H + 2) * 64]; nb1 = wp[T1 + (2 * H + 3) * 64];
+        }
+#define LSNF_MFMA2(WA, WB, G)                                                                         \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(WA[0], in[kt][4 * (G) + 0], acc0, 0, 0, 0);       \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(WB[0], in[kt][4 * (G) + 0], acc1, 0, 0, 0);       \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(WA[1], in[kt][4 * (G) + 1], acc0, 0, 0, 0);       \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(WB[1], in[kt][4 * (G) + 1], acc1, 0, 0, 0);       \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(WA[2], in[kt][4 * (G) + 2], acc0, 0, 0, 0);       \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(WB[2], in[kt][4 * (G) + 2], acc1, 0, 0, 0);       \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(WA[3], in[kt][4 * (G) + 3], acc0, 0, 0, 0);       \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(WB[3], in[kt][4 * (G) + 3], acc1, 0, 0, 0);
+        LSNF_MFMA2(a0, b0, g0) LSNF_MFMA2(a1, b1, g0 + 1)
+#undef LSNF_MFMA2
+        if (H + 1 < 2 * KT) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+    }
+}
+
+// ---- one GEMM stage: out[t] = post(init(t) + W_t^T in), t < NT, streamed as panel PAIRS -----------------
+// gsrc: this stage's packed panels (n-tile major, KT k-tiles each).  gnext/NEXT_KTC: first panel (pair) of
+// whatever follows this stage (NEXT_KTC = its k-tiles x its tile count; gnext == nullptr: nothing follows).
+template <int NT, int KT, int NEXT_KTC, class Init, class Post>
+__device__ __forceinline__ void lsnf_gemm_stage(LsnfPipe& pipe, const float* gsrc, const float* gnext, f32x16* out,
+                                                const f32x16* in, Init&& init, Post&& post) {
+    constexpr int NSP = (NT + 1) / 2;
+    lsnf_static_for<NSP>([&](auto qc) {
+        constexpr int q = decltype(qc)::value, t0 = 2 * q, cnt = (NT - t0 >= 2) ? 2 : 1;
+        const float* lb;
+        if constexpr (q + 1 < NSP) {
+            constexpr int cn = (NT - (t0 + 2) >= 2) ? 2 : 1;
+            lb = pipe.template acquire<KT * cn>(gsrc + (t0 + 2) * KT * LSNF_FRAG_FLOATS);
+        } else {
+            lb = pipe.template acquire<NEXT_KTC>(gnext);
+        }
+        out[t0] = init(t0);
+        if constexpr (cnt == 2) {
+            out[t0 + 1] = init(t0 + 1);
+            lsnf_panel_mma2<KT>(out[t0], out[t0 + 1], in, lb, pipe.lane);
+            out[t0 + 1] = post(out[t0 + 1], t0 + 1);
+        } else {
+            lsnf_panel_mma<KT>(out[t0], in, lb, pipe.lane);
+        }
+        out[t0] = post(out[t0], t0);
+    });
+}
+// k-tiles x tiles of the FIRST panel pair of a stage with NT tiles of KT k-tiles
+__device__ __forceinline__ constexpr int lsnf_first_ktc(int NT, int KT) { return KT * (NT >= 2 ? 2 : 1); }
 
 // bit r of the result = (a[r] > 0): relu mask of one tile, for the backward pass
 __device__ __forceinline__ unsigned lsnf_posmask16(const f32x16& a) {

@@ -10,35 +10,25 @@
 // Every GEMM runs on v_mfma_f32_32x32x2_f32 with the WEIGHTS as the A operand (output feature
 // on the row index) and the ACTIVATIONS as the B operand, so a GEMM's accumulator registers are
 // directly the next GEMM's B operand (lsnf_layout.h).  Weights stream L2 -> LDS by LDS-DMA in
-// panels (one n-tile x all k-tiles, <= 16 KiB), double-buffered, one barrier per panel.
+// panel pairs (two n-tiles x all k-tiles, <= 32 KiB, two independent accumulator chains), double-buffered,
+// one barrier per pair.
 #include "lsnf_device.h"
 
 namespace {
 
-template <int N, class F, int I = 0>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<N, F, I + 1>(static_cast<F&&>(f));
-    }
-}
-
 template <int HT_, int WT_>
 struct FwdCfg {
     static constexpr int HT = HT_, WT = WT_, NZT = 2 * HT_;
-    static constexpr int P1 = NZT, P2 = WT, P3 = WT, P4 = 2 * HT;  // panels per stage
+    static constexpr int P1 = NZT, P2 = WT, P3 = WT, P4 = 2 * HT;  // n-tiles (single panels) per stage
     static constexpr int NP = P1 + P2 + P3 + P4;
     static constexpr int KT1 = NZT, KT2 = HT, KT3 = WT, KT4 = WT;
     static constexpr int MAXKT = (NZT > WT ? NZT : WT);
-    static constexpr int SLOT = MAXKT * LSNF_FRAG_FLOATS;
-    static constexpr int BLOCK_FLOATS = LSNF_FRAG_FLOATS * (P1 * KT1 + P2 * KT2 + P3 * KT3 + P4 * KT4);
+    static constexpr int SLOT = 2 * MAXKT * LSNF_FRAG_FLOATS;      // a panel PAIR
+    static constexpr int OFF_S2 = LSNF_FRAG_FLOATS * P1 * KT1;
+    static constexpr int OFF_S3 = OFF_S2 + LSNF_FRAG_FLOATS * P2 * KT2;
+    static constexpr int OFF_S4 = OFF_S3 + LSNF_FRAG_FLOATS * P3 * KT3;
+    static constexpr int BLOCK_FLOATS = OFF_S4 + LSNF_FRAG_FLOATS * P4 * KT4;
     static constexpr int CONST_FLOATS = 32 * NP + 32;
-    static constexpr int kt_of(int p) { return p < P1 ? KT1 : (p < P1 + P2 ? KT2 : KT3); }
-    static constexpr int off_of(int p) {  // float offset of panel p inside a block's stream
-        int o = 0;
-        for (int q = 0; q < p; ++q) o += kt_of(q) * LSNF_FRAG_FLOATS;
-        return o;
-    }
 };
 
 struct FwdArgs {
@@ -51,7 +41,25 @@ struct FwdArgs {
     float* ll_out;
     float* z_saved;
     int B, nz, half, n_blocks, vec4;
+    int stagger_mode, stagger_count;   // see lsnf_stagger() in lsnf_device.h
+    unsigned long long* stamps;        // LSNF_STAMPS diagnostic build only: [grid][4 waves][64] shader-clock stamps
 };
+
+#ifdef LSNF_STAMPS
+#define LSNF_STAMP(i)                                                                                   \
+    do { __builtin_amdgcn_sched_barrier(0);                                                             \
+         unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+         __builtin_amdgcn_sched_barrier(0);                                                             \
+         if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wave) * 64 + (i)] = t_; } while (0)
+#define LSNF_STAMP_RT(i)                                                                                \
+    do { __builtin_amdgcn_sched_barrier(0);                                                             \
+         unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+         __builtin_amdgcn_sched_barrier(0);                                                             \
+         if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wave) * 64 + (i)] = t_; } while (0)
+#else
+#define LSNF_STAMP(i) do {} while (0)
+#define LSNF_STAMP_RT(i) do {} while (0)
+#endif
 
 template <class C>
 __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_fwd_kernel(const FwdArgs a) {
@@ -64,8 +72,13 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_fwd_kernel(const FwdA
     const int lane = tid & 63;
     const int m = lane & 31, h = lane >> 5;
 
-    // prologue: first panel in flight, constants to LDS, latent rows to registers
-    lsnf_issue_panel<C::kt_of(0)>(a.panels, buf0, wave, lane);
+    LSNF_STAMP(0);
+    LSNF_STAMP_RT(50);
+    lsnf_stagger(a.stagger_mode, a.stagger_count);
+    // prologue: first panel pair in flight, constants to LDS, latent rows to registers
+    LsnfPipe pipe;
+    pipe.buf0 = buf0; pipe.slot = C::SLOT; pipe.wave = wave; pipe.lane = lane;
+    pipe.prime<lsnf_first_ktc(C::P1, C::KT1)>(a.panels);
     for (int i = tid; i < a.n_blocks * C::CONST_FLOATS; i += LSNF_WG_THREADS) cst[i] = a.consts[i];
 
     const long sample = ((long)blockIdx.x * LSNF_WG_WAVES + wave) * 32 + m;
@@ -84,58 +97,41 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_fwd_kernel(const FwdA
     float ell = a.objective ? a.objective[row] : 0.0f;
 #endif
 
+    LSNF_STAMP(1);
     for (int blk = 0; blk < a.n_blocks; ++blk) {
         const float* cb = cst + blk * C::CONST_FLOATS;
         const float* gblk = a.panels + (size_t)blk * C::BLOCK_FLOATS;
         const bool more = blk + 1 < a.n_blocks;
 
-        // acquire<P>: panel P of this block is ready in buffer P&1 after this; prefetch P+1.
-        auto acquire = [&](auto Pc) -> const float* {
-            constexpr int P = decltype(Pc)::value;
-            lsnf_panel_barrier();
-            float* nxt = buf0 + ((P + 1) & 1) * C::SLOT;
-            if constexpr (P + 1 < C::NP) {
-                lsnf_issue_panel<C::kt_of(P + 1)>(gblk + C::off_of(P + 1), nxt, wave, lane);
-            } else {
-                if (more) lsnf_issue_panel<C::kt_of(0)>(gblk + C::BLOCK_FLOATS, nxt, wave, lane);
-            }
-            return buf0 + (P & 1) * C::SLOT;
-        };
+        const float* gnext = more ? gblk + C::BLOCK_FLOATS : nullptr;
+        auto keep = [](f32x16 acc, int) { return acc; };
+        auto relu = [](f32x16 acc, int) { return lsnf_relu16(acc); };
 
         // ---- S1: v = Wa^T x + ca  (actnorm model.py:244,268 folded into the 1x1 conv :187) ----
         f32x16 v[NZT];
-        static_for<NZT>([&](auto nt) {
-            const float* lb = acquire(std::integral_constant<int, nt.value>{});
-            v[nt] = lsnf_bias_init(cb + 32 * nt, h);
-            lsnf_panel_mma<C::KT1>(v[nt], x, lb, lane);
-        });
+        lsnf_gemm_stage<C::P1, C::KT1, lsnf_first_ktc(C::P2, C::KT2)>(
+            pipe, gblk, gblk + C::OFF_S2, v, x, [&](int t) { return lsnf_bias_init(cb + 32 * t, h); }, keep);
+        LSNF_STAMP(2 + 6 * blk + 0);
         // logdet += sum(3*logs) (model.py:273-276); logdet += log|det W| (model.py:182,189)
         ell = ell + cb[32 * C::NP + 0];
         ell = ell + cb[32 * C::NP + 1];
-
         // ---- S2: h1 = relu(actnorm(v1 @ W1))  (model.py:326-328,307) ----
         f32x16 h1[WT];
-        static_for<WT>([&](auto nt) {
-            const float* lb = acquire(std::integral_constant<int, C::P1 + nt.value>{});
-            h1[nt] = lsnf_bias_init(cb + 32 * (C::P1 + nt), h);
-            lsnf_panel_mma<C::KT2>(h1[nt], v, lb, lane);
-            h1[nt] = lsnf_relu16(h1[nt]);
-        });
+        lsnf_gemm_stage<C::P2, C::KT2, lsnf_first_ktc(C::P3, C::KT3)>(
+            pipe, gblk + C::OFF_S2, gblk + C::OFF_S3, h1, v, [&](int t) { return lsnf_bias_init(cb + 32 * (C::P1 + t), h); }, relu);
+        LSNF_STAMP(2 + 6 * blk + 1);
         // ---- S3: h2 = relu(actnorm(h1 @ W2))  (model.py:326-328,308) ----
         f32x16 h2[WT];
-        static_for<WT>([&](auto nt) {
-            const float* lb = acquire(std::integral_constant<int, C::P1 + C::P2 + nt.value>{});
-            h2[nt] = lsnf_bias_init(cb + 32 * (C::P1 + C::P2 + nt), h);
-            lsnf_panel_mma<C::KT3>(h2[nt], h1, lb, lane);
-            h2[nt] = lsnf_relu16(h2[nt]);
-        });
+        lsnf_gemm_stage<C::P3, C::KT3, lsnf_first_ktc(C::P4, C::KT4)>(
+            pipe, gblk + C::OFF_S3, gblk + C::OFF_S4, h2, h1,
+            [&](int t) { return lsnf_bias_init(cb + 32 * (C::P1 + C::P2 + t), h); }, relu);
+        LSNF_STAMP(2 + 6 * blk + 2);
         // ---- S4: shift t / pre-sigmoid p = fc_zeros(h2), de-interleaved (model.py:347-349,411-413) ----
         f32x16 tp[2 * HT];
-        static_for<2 * HT>([&](auto nt) {
-            const float* lb = acquire(std::integral_constant<int, C::P1 + C::P2 + C::P3 + nt.value>{});
-            tp[nt] = lsnf_bias_init(cb + 32 * (C::P1 + C::P2 + C::P3 + nt), h);
-            lsnf_panel_mma<C::KT4>(tp[nt], h2, lb, lane);
-        });
+        lsnf_gemm_stage<C::P4, C::KT4, lsnf_first_ktc(C::P1, C::KT1)>(
+            pipe, gblk + C::OFF_S4, gnext, tp, h2,
+            [&](int t) { return lsnf_bias_init(cb + 32 * (C::P1 + C::P2 + C::P3 + t), h); }, keep);
+        LSNF_STAMP(2 + 6 * blk + 3);
         // ---- coupling + per-sample log-scale reduction (model.py:414-418), concat (:422) ----
         float lsum = 0.0f;
 #pragma unroll
@@ -150,6 +146,7 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_fwd_kernel(const FwdA
             }
         }
         ell = ell + lsnf_pair_sum(lsum);
+        LSNF_STAMP(2 + 6 * blk + 4);
 
         if (a.z_saved != nullptr && more && live)
             lsnf_store_rows<HT>(x, a.z_saved + (size_t)blk * a.B * a.nz, sample, a.nz, a.half, h, a.vec4 != 0);
@@ -172,6 +169,10 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_fwd_kernel(const FwdA
             if (a.ll_out) a.ll_out[sample] = (-0.5f * ss + 1.8378770664093453f) + ell;
         }
     }
+    LSNF_STAMP(40);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LSNF_STAMP(41);
+    LSNF_STAMP_RT(51);
 }
 
 template <class C>
@@ -191,6 +192,10 @@ hipError_t launch_fwd(const FwdArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+#ifdef LSNF_STAMPS
+unsigned long long* g_lsnf_stamps = nullptr;
+extern "C" unsigned long long* lsnf_debug_stamps(void) { return g_lsnf_stamps; }
+#endif
 // host-side dispatcher (called from lsnf_api.hip)
 hipError_t lsnf_launch_forward(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                const float* z_in, const float* objective, float* z_out, float* logdet_out,
@@ -200,6 +205,16 @@ hipError_t lsnf_launch_forward(const LsnfGeo& g, const float* plan, int first_bl
     a.panels = plan + g.off_fwd_panels + (size_t)first_block * g.fwd_block_floats;
     a.z_in = z_in; a.objective = objective; a.z_out = z_out; a.logdet_out = logdet_out; a.ll_out = ll_out;
     a.z_saved = z_saved; a.B = B; a.nz = g.nz; a.half = g.half; a.n_blocks = n_blocks; a.vec4 = vec4;
+    lsnf_stagger_config(&a.stagger_mode, &a.stagger_count);
+    a.stamps = nullptr;
+#ifdef LSNF_STAMPS
+    {   // diagnostic build: a leaked device buffer, address published through LSNF_STAMPS_PTR (see tools/stamps.py)
+        static unsigned long long* buf = nullptr;
+        if (!buf) { if (hipMalloc(&buf, sizeof(unsigned long long) * 64 * 4 * 4096) != hipSuccess) buf = nullptr; }
+        a.stamps = (B <= 128 * 4096) ? buf : nullptr;
+        extern unsigned long long* g_lsnf_stamps; g_lsnf_stamps = buf;
+    }
+#endif
     if (g.HT == 1 && g.WT == 1) return launch_fwd<FwdCfg<1, 1>>(a, stream);
     if (g.HT == 2 && g.WT == 2) return launch_fwd<FwdCfg<2, 2>>(a, stream);
     if (g.HT == 2 && g.WT == 4) return launch_fwd<FwdCfg<2, 4>>(a, stream);
