@@ -25,68 +25,96 @@ __host__ __device__ static inline size_t scratch_block_doubles(int nz) { return 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lsnf_gj_kernel(LsnfParamPtrs pp, int nz, double* scratch) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int n = nz, ld = n + 1;
-    double* A = sm;                       // n * ld
-    double* colv = A + (size_t)n * ld;    // n   (eliminated column)
-    double* red = colv + n;               // 256 (pivot search values)
-    int* redi = (int*)(red + 256);        // 256 (pivot search rows)
-    int* perm = redi + 256;               // n
-    const int tid = threadIdx.x;
+    const int n = nz, ld = n + 1;         // odd leading dimension: column walks are bank-conflict free
+    double* A = sm;                       // n * ld   in-place inverse
+    double* prow = A + (size_t)n * ld;    // n   scaled pivot row of the current step
+    double* colv = prow + n;              // n   eliminated column of the current step
+    int* perm = (int*)(colv + n);         // n   pivot row chosen at step c
+    int* cmap = perm + n;                 // n   final column un-permutation
+    int* pivot = cmap + n;                // 1
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ry = tid >> 4, cx = tid & 15;            // 16 x 16 thread grid over the matrix
     const int blk = blockIdx.x;
     const float* W = pp.p[blk * 12 + P_W];
-    for (int i = tid; i < n * n; i += 256) A[(i / n) * ld + (i % n)] = (double)W[i];
+    for (int r = ry; r < n; r += 16)
+        for (int j = cx; j < n; j += 16) A[r * ld + j] = (double)W[r * n + j];
     __syncthreads();
-    double logabs = 0.0;  // meaningful in thread 0
+    double logabs = 0.0;                  // meaningful in thread 0
     for (int c = 0; c < n; ++c) {
-        // pivot search over rows c..n-1 of column c
-        double best = -1.0; int bi = c;
-        for (int r = c + tid; r < n; r += 256) {
-            const double v = fabs(A[r * ld + c]);
-            if (v > best) { best = v; bi = r; }
-        }
-        red[tid] = best; redi[tid] = bi;
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if (tid < s) {
-                const double o = red[tid + s]; const int oi = redi[tid + s];
-                if (o > red[tid] || (o == red[tid] && oi < redi[tid])) { red[tid] = o; redi[tid] = oi; }
+        // (1) partial pivoting: wave 0 scans rows c..n-1 of column c, shuffle arg-max (ties -> lowest row)
+        if (wave == 0) {
+            double best = -1.0; int bi = c;
+            for (int r = c + lane; r < n; r += 64) {
+                const double v = fabs(A[r * ld + c]);
+                if (v > best) { best = v; bi = r; }
             }
-            __syncthreads();
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ob = __shfl_xor(best, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (lane == 0) { *pivot = bi; perm[c] = bi; }
         }
-        const int p = redi[0];
-        if (tid == 0) perm[c] = p;
-        // swap rows c <-> p
-        if (p != c)
-            for (int j = tid; j < n; j += 256) { const double t = A[c * ld + j]; A[c * ld + j] = A[p * ld + j]; A[p * ld + j] = t; }
         __syncthreads();
-        const double pv = A[c * ld + c];
-        if (tid == 0) logabs += log(fabs(pv));
-        for (int r = tid; r < n; r += 256) colv[r] = A[r * ld + c];
+        const int p = *pivot;
+        // (2) read phase: rows c and p (to be exchanged) and column c
+        const double pv = A[p * ld + c];
+        double a_c = 0.0, a_p = 0.0, cv = 0.0;
+        if (tid < n) { a_c = A[c * ld + tid]; a_p = A[p * ld + tid]; }
+        else if (tid < 2 * n) { const int r = tid - n; cv = A[r * ld + c]; }
         __syncthreads();
-        // scale pivot row (in-place inverse: pivot slot becomes 1/pv)
+        // (3) write phase: exchange, scale the pivot row (pivot slot becomes 1/pv), publish row / column
         const double ipv = 1.0 / pv;
-        for (int j = tid; j < n; j += 256) A[c * ld + j] = (j == c ? 1.0 : A[c * ld + j]) * ipv;
+        if (tid == 0) logabs += log(fabs(pv));
+        if (tid < n) {
+            const int j = tid;
+            const double pr = (j == c ? 1.0 : a_p) * ipv;
+            if (p != c) A[p * ld + j] = a_c;
+            A[c * ld + j] = pr;
+            prow[j] = pr;
+        } else if (tid < 2 * n) {
+            // multipliers of the elimination = column c AFTER the exchange: rows other than c, p keep theirs;
+            // row p now holds the old row c, whose entry old A[c][c] was read by the thread of r == c.
+            const int r = tid - n;
+            if (r == c) { if (p != c) colv[p] = cv; }
+            else if (r != p) colv[r] = cv;
+        }
         __syncthreads();
-        // eliminate column c from every other row
-        for (int i = tid; i < n * n; i += 256) {
-            const int r = i / n, j = i % n;
-            if (r != c) {
-                const double f = colv[r];
-                const double base = (j == c) ? 0.0 : A[r * ld + j];
-                A[r * ld + j] = base - f * A[c * ld + j];
+        // (4) eliminate column c from every row but c: 8 x 8 elements per thread, fully unrolled so that the
+        //     LDS reads of a thread are all in flight together (one workgroup per CU: latency, not bandwidth)
+        {
+            double pr[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) { const int j = cx + 16 * jj; pr[jj] = (j < n) ? prow[j] : 0.0; }
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = ry + 16 * rr;
+                if (r < n && r != c) {
+                    const double f = colv[r];
+                    double av[8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) { const int j = cx + 16 * jj; av[jj] = (j < n && j != c) ? A[r * ld + j] : 0.0; }
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) { const int j = cx + 16 * jj; if (j < n) A[r * ld + j] = av[jj] - f * pr[jj]; }
+                }
             }
         }
         __syncthreads();
     }
-    // undo the row interchanges as column interchanges, in reverse order
-    for (int c = n - 1; c >= 0; --c) {
-        const int p = perm[c];
-        if (p != c)
-            for (int r = tid; r < n; r += 256) { const double t = A[r * ld + c]; A[r * ld + c] = A[r * ld + p]; A[r * ld + p] = t; }
-        __syncthreads();
+    // undo the row interchanges as column interchanges (reverse order), composed into one map by thread 0
+    if (tid == 0) {
+        for (int j = 0; j < n; ++j) cmap[j] = j;
+        for (int c = n - 1; c >= 0; --c) {
+            const int p = perm[c];
+            if (p != c) { const int t = cmap[c]; cmap[c] = cmap[p]; cmap[p] = t; }
+        }
     }
+    __syncthreads();
     double* out = scratch + (size_t)blk * scratch_block_doubles(nz);
-    for (int i = tid; i < n * n; i += 256) out[i] = A[(i / n) * ld + (i % n)];
+    // after the swaps, position j holds what the un-swapped matrix has in column cmap[j]
+    for (int r = ry; r < n; r += 16)
+        for (int j = cx; j < n; j += 16) out[r * n + j] = A[r * ld + cmap[j]];
     if (tid == 0) {
         const float* logs = pp.p[blk * 12 + P_ALOGS];
         // reference: torch.sum(logs * 3) in fp32 (model.py:264,273); each term logs*3 is rounded
@@ -259,7 +287,7 @@ hipError_t lsnf_launch_prepare(const LsnfGeo& g, const float* const* params_host
     for (int i = 0; i < g.depth * 12; ++i) pp.p[i] = params_host[i];
     for (int i = g.depth * 12; i < LSNF_MAX_DEPTH * 12; ++i) pp.p[i] = nullptr;
     const int n = g.nz;
-    const size_t lds = sizeof(double) * ((size_t)n * (n + 1) + n + 256) + sizeof(int) * (256 + n);
+    const size_t lds = sizeof(double) * ((size_t)n * (n + 1) + 2 * n) + sizeof(int) * (2 * n + 4);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)lsnf_gj_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
