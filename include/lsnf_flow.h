@@ -115,6 +115,19 @@ int lsnf_backward_z(const float* plan, int nz, int width, int depth, int couplin
                     const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
                     float* g_z_in, void* stream);
 
+/* ---- fused Langevin update: replaces train.py:317-329 after the forward ---------------------
+ * One launch computes g_f = d(-sum ll)/dz (as lsnf_backward_z with ll_mode=1, ll_scale=-1) and applies
+ *     z_new = z_cur - 0.5*s^2 * (grad_g + g_f) + s * noise          (train.py:324,326)
+ * plus the per-sample gradient norms of train.py:328-329 (the caller takes their mean).
+ *   z_cur  (B,nz) current latents (the z that lsnf_forward was run on); z_out / z_saved from that forward
+ *   grad_g (B,nz) or NULL (= 0): the generator's gradient z_grad_g (train.py:314)
+ *   noise  (B,nz) or NULL (= no noise, as the test-time sampler train.py:624-625): N(0,1) draws
+ *   z_new  (B,nz), may alias z_cur (in-place update);  gf_norm, gg_norm: (B) or NULL. */
+int lsnf_langevin_step(const float* plan, int nz, int width, int depth, int coupling, int B,
+                       const float* z_cur, const float* z_out, const float* z_saved,
+                       const float* grad_g, const float* noise, float step_size,
+                       float* z_new, float* gf_norm, float* gg_norm, void* stream);
+
 /* ---- backward w.r.t. the parameters: replaces `loss_f.backward()` (train.py:406-411) --------
  * Gradients of L w.r.t. the 12 live tensors of every block (same order as lsnf_prepare), for the
  * upstream gradients described under lsnf_backward_z (train.py:410: L = -mean ll -> ll_mode=1,

@@ -29,6 +29,9 @@ _SIGNATURES = {
                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lsnf_backward_z": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
+    "lsnf_langevin_step": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                   c_void_p, c_void_p, c_void_p, c_void_p]),
     "lsnf_backward_params_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "lsnf_backward_params": (c_int, [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
                                      c_int, c_int, c_int, c_int, c_int,

@@ -19,7 +19,8 @@ hipError_t lsnf_launch_reverse(const LsnfGeo& g, const float* plan, int B, const
                                float* z_out, float* objective_out, int vec4, hipStream_t stream);
 hipError_t lsnf_launch_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
                                   const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
-                                  float* g_z_in, float* dump, float* gl_total, int vec4, hipStream_t stream);
+                                  float* g_z_in, float* dump, float* gl_total, int vec4, hipStream_t stream,
+                                  const LsnfLangevinArgs* lv = nullptr);
 hipError_t lsnf_launch_backward_params(const LsnfGeo& g, const float* plan, const float* const* params_host,
                                        float* const* grads_host, int B, const float* z_in, const float* z_out,
                                        const float* z_saved, const float* g_z1, const float* g_logdet, int ll_mode,
@@ -148,6 +149,26 @@ int lsnf_backward_z(const float* plan, int nz, int width, int depth, int couplin
     hipError_t e = lsnf_launch_backward_z(g, plan, B, z_out, z_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, nullptr,
                                           nullptr, vec4, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "lsnf_backward_z launch");
+    return LSNF_OK;
+}
+
+int lsnf_langevin_step(const float* plan, int nz, int width, int depth, int coupling, int B, const float* z_cur,
+                       const float* z_out, const float* z_saved, const float* grad_g, const float* noise, float step_size,
+                       float* z_new, float* gf_norm, float* gg_norm, void* stream) {
+    LsnfGeo g;
+    if (int rc = geo_or_fail(&g, nz, width, depth, coupling)) return rc;
+    if (B < 0 || B > (1 << 28)) return fail(LSNF_E_ARG, "lsnf_langevin_step: B=%d out of range", B);
+    if (B == 0) return LSNF_OK;
+    if (!plan || !z_cur || !z_out || !z_new || (depth > 1 && !z_saved)) return fail(LSNF_E_ARG, "lsnf_langevin_step: NULL argument");
+    if (!aligned16(plan)) return fail(LSNF_E_ARG, "lsnf_langevin_step: plan must be 16-byte aligned");
+    if (!aligned4(z_cur) || !aligned4(z_out) || !aligned4(z_saved) || !aligned4(grad_g) || !aligned4(noise) || !aligned4(z_new) ||
+        !aligned4(gf_norm) || !aligned4(gg_norm))
+        return fail(LSNF_E_ARG, "lsnf_langevin_step: tensors must be 4-byte aligned");
+    const int vec4 = (g.half % 4 == 0) && aligned16(z_out) && (z_saved == nullptr || aligned16(z_saved));
+    LsnfLangevinArgs lv = {z_cur, grad_g, noise, z_new, gf_norm, gg_norm, step_size};
+    hipError_t e = lsnf_launch_backward_z(g, plan, B, z_out, z_saved, nullptr, nullptr, /*ll_mode=*/1, /*ll_scale=*/-1.0f,
+                                          nullptr, nullptr, nullptr, vec4, (hipStream_t)stream, &lv);
+    if (e != hipSuccess) return hip_fail(e, "lsnf_langevin_step launch");
     return LSNF_OK;
 }
 

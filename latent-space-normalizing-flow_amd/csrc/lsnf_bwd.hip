@@ -39,6 +39,9 @@ struct BwdArgs {
     float* g_z_in;          // may be NULL when only parameter gradients are wanted
     float* dump;            // DUMP variant: per-block intermediates for the parameter gradients (lsnf_layout.h)
     float* gl_total;        // DUMP variant: += sum_b dL/dlogdet_b
+    // fused Langevin update (train.py:324-329): z_new = z_cur - 0.5 s^2 (grad_g + g_z_in) + s * noise
+    const float* z_cur; const float* grad_g; const float* noise; float* z_new; float* gf_norm; float* gg_norm;
+    float step;
     float ll_scale;
     int ll_mode, B, nz, half, width, depth, vec4;
 };
@@ -223,6 +226,39 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_bwd_z_kernel(const Bw
         });
     }
     if (live && a.g_z_in) lsnf_store_rows<HT>(gx, a.g_z_in, sample, a.nz, a.half, h, vec4);
+    if (a.z_new) {   // wave-uniform: fused Langevin update, tile by tile (keeps the register footprint flat)
+        const float coef = 0.5f * a.step * a.step;
+        float gf2 = 0.0f, gg2 = 0.0f;
+        const float* zr = a.z_cur + row * (long)a.nz;
+        float* zo = a.z_new + row * (long)a.nz;
+#pragma unroll
+        for (int t = 0; t < NZT; ++t) {
+            const f32x16 zc = lsnf_load_tile<HT>(t, zr, a.half, h, false);
+            f32x16 g = gx[t];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gf2 += g[r] * g[r];
+            if (a.grad_g) {
+                const f32x16 gg = lsnf_load_tile<HT>(t, a.grad_g + row * (long)a.nz, a.half, h, false);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { gg2 += gg[r] * gg[r]; g[r] = gg[r] + g[r]; }   // z_grad_g + z_grad_f (train.py:324)
+            }
+            f32x16 zn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zn[r] = zc[r] - coef * g[r];
+            if (a.noise) {
+                const f32x16 nv = lsnf_load_tile<HT>(t, a.noise + row * (long)a.nz, a.half, h, false);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zn[r] = zn[r] + a.step * nv[r];                    // train.py:326
+            }
+            if (live) lsnf_store_tile<HT>(t, zn, zo, a.half, h, false);
+        }
+        gf2 = lsnf_pair_sum(gf2);
+        gg2 = lsnf_pair_sum(gg2);
+        if (live && h == 0) {
+            if (a.gf_norm) a.gf_norm[sample] = sqrtf(gf2);     // per-sample norms of train.py:328-329
+            if (a.gg_norm) a.gg_norm[sample] = sqrtf(gg2);
+        }
+    }
 }
 
 template <class C, bool DUMP>
@@ -245,9 +281,13 @@ hipError_t launch_bwd(const BwdArgs& a, hipStream_t stream) {
 // (and accumulates sum dL/dlogdet into gl_total) that lsnf_params.hip turns into parameter gradients.
 hipError_t lsnf_launch_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
                                   const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
-                                  float* g_z_in, float* dump, float* gl_total, int vec4, hipStream_t stream) {
+                                  float* g_z_in, float* dump, float* gl_total, int vec4, hipStream_t stream,
+                                  const LsnfLangevinArgs* lv) {
     BwdArgs a;
     a.dump = dump; a.gl_total = gl_total; a.width = g.width;
+    a.z_cur = nullptr; a.grad_g = nullptr; a.noise = nullptr; a.z_new = nullptr; a.gf_norm = nullptr; a.gg_norm = nullptr; a.step = 0.f;
+    if (lv) { a.z_cur = lv->z_cur; a.grad_g = lv->grad_g; a.noise = lv->noise; a.z_new = lv->z_new; a.gf_norm = lv->gf_norm;
+              a.gg_norm = lv->gg_norm; a.step = lv->step; }
     a.fwd_consts = plan + g.off_fwd_const; a.fwd_panels = plan + g.off_fwd_panels; a.bwd_panels = plan + g.off_bwd_panels;
     a.z_out = z_out; a.z_saved = z_saved; a.g_z1 = g_z1; a.g_logdet = g_logdet; a.g_z_in = g_z_in;
     a.ll_scale = ll_scale; a.ll_mode = ll_mode; a.B = B; a.nz = g.nz; a.half = g.half; a.depth = g.depth; a.vec4 = vec4;

@@ -165,28 +165,53 @@ __device__ __forceinline__ void lsnf_sigmoid_logsig(float p, float& sig, float& 
 __device__ __forceinline__ float lsnf_pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 
 // ---- latent rows <-> split-pad register tiles -------------------------------------------------
-// row: sample index (already clamped to [0,B)), x[t][r] <- feature nat(32*t + o(r,h)).
+// row: sample index (already clamped to [0,B)), tile t of the split-pad row: x[r] <- feature nat(32*t + o(r,h)).
+template <int HT>
+__device__ __forceinline__ f32x16 lsnf_load_tile(int t, const float* __restrict__ zr, int half, int h, bool vec4) {
+    f32x16 x;
+    const int hh = t / HT, tt = t % HT;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int f0 = 32 * tt + 8 * g + 4 * h;
+        const int col0 = hh * half + f0;
+        if (vec4) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (f0 < half) v = *reinterpret_cast<const f32x4*>(zr + col0);
+            x[4 * g + 0] = v[0]; x[4 * g + 1] = v[1]; x[4 * g + 2] = v[2]; x[4 * g + 3] = v[3];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[4 * g + j] = (f0 + j < half) ? zr[col0 + j] : 0.0f;
+        }
+    }
+    return x;
+}
+
+template <int HT>
+__device__ __forceinline__ void lsnf_store_tile(int t, const f32x16& x, float* __restrict__ zr, int half, int h, bool vec4) {
+    const int hh = t / HT, tt = t % HT;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int f0 = 32 * tt + 8 * g + 4 * h;
+        const int col0 = hh * half + f0;
+        if (vec4) {
+            if (f0 < half) {
+                f32x4 v = {x[4 * g + 0], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
+                *reinterpret_cast<f32x4*>(zr + col0) = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (f0 + j < half) zr[col0 + j] = x[4 * g + j];
+        }
+    }
+}
+
 template <int HT>
 __device__ __forceinline__ void lsnf_load_rows(f32x16* x, const float* __restrict__ z, long row, int nz, int half,
                                                int h, bool vec4) {
     const float* zr = z + row * (long)nz;
 #pragma unroll
-    for (int t = 0; t < 2 * HT; ++t) {
-        const int hh = t / HT, tt = t % HT;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int f0 = 32 * tt + 8 * g + 4 * h;
-            const int col0 = hh * half + f0;
-            if (vec4) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (f0 < half) v = *reinterpret_cast<const f32x4*>(zr + col0);
-                x[t][4 * g + 0] = v[0]; x[t][4 * g + 1] = v[1]; x[t][4 * g + 2] = v[2]; x[t][4 * g + 3] = v[3];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) x[t][4 * g + j] = (f0 + j < half) ? zr[col0 + j] : 0.0f;
-            }
-        }
-    }
+    for (int t = 0; t < 2 * HT; ++t) x[t] = lsnf_load_tile<HT>(t, zr, half, h, vec4);
 }
 
 template <int HT>
@@ -194,24 +219,7 @@ __device__ __forceinline__ void lsnf_store_rows(const f32x16* x, float* __restri
                                                 int h, bool vec4) {
     float* zr = z + row * (long)nz;
 #pragma unroll
-    for (int t = 0; t < 2 * HT; ++t) {
-        const int hh = t / HT, tt = t % HT;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int f0 = 32 * tt + 8 * g + 4 * h;
-            const int col0 = hh * half + f0;
-            if (vec4) {
-                if (f0 < half) {
-                    f32x4 v = {x[t][4 * g + 0], x[t][4 * g + 1], x[t][4 * g + 2], x[t][4 * g + 3]};
-                    *reinterpret_cast<f32x4*>(zr + col0) = v;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (f0 + j < half) zr[col0 + j] = x[t][4 * g + j];
-            }
-        }
-    }
+    for (int t = 0; t < 2 * HT; ++t) lsnf_store_tile<HT>(t, x[t], zr, half, h, vec4);
 }
 
 // ---- double-buffered weight-panel pipeline with a run-time buffer parity -------------------------

@@ -41,6 +41,12 @@ struct LsnfGeo {
     size_t total_floats;
 };
 
+// optional tail of the backward kernel: the Langevin update of train.py:324-329
+struct LsnfLangevinArgs {
+    const float* z_cur; const float* grad_g; const float* noise;
+    float* z_new; float* gf_norm; float* gg_norm; float step;
+};
+
 static inline int lsnf_ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // Chooses the kernel instantiation (HT, WT) in {(1,1),(2,2),(2,4)} that covers (half, width).

@@ -191,6 +191,31 @@ def backward_z(plan: FlowPlan, z_out: torch.Tensor, z_saved: Optional[torch.Tens
     return g_in
 
 
+def langevin_step(plan: FlowPlan, z: torch.Tensor, grad_g: Optional[torch.Tensor], noise: Optional[torch.Tensor],
+                  step_size: float, *, inplace: bool = False, want_norms: bool = True):
+    """One flow-prior Langevin update (train.py:316-329) in two launches: forward (keeps block outputs) and the
+    fused backward+update.  Returns (z_new, ll, gf_norm, gg_norm); ll is the log-prob of the INPUT z
+    (f_log_lkhd = -ll.sum(), train.py:320)."""
+    lib = _lib.load()
+    _need_cuda(z, "z")
+    B = z.shape[0]
+    for name, t in (("grad_g", grad_g), ("noise", noise)):
+        if t is not None:
+            _need_cuda(t, name)
+            if t.shape != z.shape:
+                raise LsnfError(f"{name} must have the shape of z")
+    z1, logdet, ll, saved = forward(plan, z, None, want_ll=True, save_for_backward=True)
+    z_new = z if inplace else torch.empty_like(z)
+    gf = torch.empty(B, dtype=torch.float32, device=z.device) if want_norms else None
+    gg = torch.empty(B, dtype=torch.float32, device=z.device) if (want_norms and grad_g is not None) else None
+    with torch.cuda.device(z.device):
+        rc = lib.lsnf_langevin_step(_ptr(plan.buf), plan.nz, plan.width, plan.depth, plan.coupling, B,
+                                    _ptr(z), _ptr(z1), _ptr(saved), _ptr(grad_g), _ptr(noise), float(step_size),
+                                    _ptr(z_new), _ptr(gf), _ptr(gg), _stream_ptr(z.device))
+    _lib.check(rc, "lsnf_langevin_step")
+    return z_new, ll, gf, gg
+
+
 def backward_params(plan: FlowPlan, params: Sequence[torch.Tensor], z_in: torch.Tensor, z_out: torch.Tensor,
                     z_saved: Optional[torch.Tensor], g_z1: Optional[torch.Tensor] = None,
                     g_logdet: Optional[torch.Tensor] = None, ll_scale: Optional[float] = None,

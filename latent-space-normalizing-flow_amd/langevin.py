@@ -1,0 +1,56 @@
+"""Caller-side harness around the flow prior: the reference's short-run Langevin sampler and flow-MLE step,
+restated (they are closures inside train.py and cannot be imported) on top of the fused kernels.
+
+  sample_langevin_post_z_with_flow  <- train.py:307-335 (training) / :602-634 (testing: 20x steps, no noise)
+  flow_mle_step                     <- train.py:404-415
+
+The generator `netG` is any `nn.Module` mapping (B, nz, 1, 1) -> images (the reference's `_netG`, stock PyTorch /
+MIOpen, is out of scope of this build and used as is); its z-gradient comes from torch autograd exactly as in the
+reference, the flow's comes from `lsnf_langevin_step` (two launches per step instead of ~750 eager kernels)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+
+def sample_langevin_post_z_with_flow(z, x, netG: nn.Module, netF, *, g_l_steps: int, g_l_step_size: float,
+                                     g_llhd_sigma: float, g_l_with_noise: bool = True,
+                                     generator: Optional[torch.Generator] = None):
+    """Returns (z_k detached (B,nz,1,1), mean |z_grad_g|, mean |z_grad_f|, f_log_lkhd of the last step's input)."""
+    z = z.clone().detach()
+    B, nz = z.shape[0], z.shape[1]
+    mse = nn.MSELoss(reduction="sum")
+    gg_norm = gf_norm = f_log_lkhd = None
+    for _ in range(g_l_steps):
+        z.requires_grad_(True)
+        x_hat = netG(z)                                                                      # train.py:312
+        g_log_lkhd = 1.0 / (2.0 * g_llhd_sigma * g_llhd_sigma) * mse(x_hat, x)               # train.py:313
+        z_grad_g = torch.autograd.grad(g_log_lkhd, z)[0]                                     # train.py:314
+        z2d = z.detach().view(B, nz)
+        noise = None
+        if g_l_with_noise:                                                                   # train.py:325-326
+            noise = torch.randn(z2d.shape, device=z2d.device, dtype=z2d.dtype, generator=generator)
+        z_new, ll, gf, gg = netF.langevin_step(z2d, z_grad_g.reshape(B, nz), noise, g_l_step_size)   # :316-326
+        f_log_lkhd = -ll.sum()                                                               # train.py:320
+        gg_norm, gf_norm = gg.mean(), gf.mean()                                              # train.py:328-329
+        z = z_new.view(B, nz, 1, 1)
+    return z.detach(), gg_norm, gf_norm, f_log_lkhd
+
+
+def flow_mle_step(netF, optF, z_g_k, f_max_norm: Optional[float] = None):
+    """train.py:404-415: one Adam step of the flow on the Langevin-inferred z.  Returns loss_f (detached)."""
+    import numpy as np
+    optF.zero_grad()
+    z2d = torch.squeeze(z_g_k)
+    z1, logdet, _ = netF(z2d, objective=torch.zeros(int(z_g_k.shape[0]), device=z2d.device), init=False)
+    prior_ll = -0.5 * (z1 ** 2)
+    prior_ll = prior_ll.flatten(1).sum(-1) + np.log(2 * np.pi)
+    ll = prior_ll + logdet
+    loss_f = -ll.mean()
+    loss_f.backward()
+    if f_max_norm is not None:
+        torch.nn.utils.clip_grad_norm_(netF.parameters(), f_max_norm)                        # train.py:413-414
+    optF.step()
+    return loss_f.detach()

@@ -247,3 +247,10 @@ class _netF(nn.Module):
         z1, logdet, ll, saved = flow.forward(plan, z.detach().contiguous(), None, want_ll=True, save_for_backward=True)
         g = flow.backward_z(plan, z1, saved, ll_scale=scale)
         return ll, g
+
+    def langevin_step(self, z, grad_g=None, noise=None, step_size=0.1, inplace=False):
+        """z <- z - 0.5 s^2 (grad_g + d(-sum ll)/dz) + s*noise (train.py:316-326), flow part fused into two launches.
+        Returns (z_new, ll_of_input_z, |grad_f| per row, |grad_g| per row or None)."""
+        return flow.langevin_step(self._plan(), z.detach().contiguous(),
+                                  None if grad_g is None else grad_g.detach().contiguous(),
+                                  None if noise is None else noise.detach().contiguous(), step_size, inplace=inplace)

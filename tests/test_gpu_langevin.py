@@ -1,0 +1,119 @@
+"""GPU: the fused Langevin update (lsnf_langevin_step) and the caller-side harness (train.py:307-335, 404-415)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import load_golden
+from oracle import flow_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lsnf():
+    import lsnf_amd
+    lsnf_amd.load_library()
+    return lsnf_amd
+
+
+def make_net(lsnf, p, nz, w, d, dev):
+    hps = types.SimpleNamespace(f_n_levels=1, f_depth=d, f_flow_permutation=2, f_width=w, f_flow_coupling=1)
+    net = lsnf._netF(hps, nz=nz)
+    net.load_state_dict(p, strict=True)
+    return net.to(dev)
+
+
+def test_fused_step_replays_reference_trajectory(lsnf, gpu_device):
+    """The noise-free K=3 trajectory captured from the reference (its own _netG gradients replayed)."""
+    p, g = load_golden("langevin_nz100_w64_B16_K3")
+    net = make_net(lsnf, p, 100, 64, 5, gpu_device)
+    z = torch.from_numpy(g["z0"]).to(gpu_device)
+    s = float(g["step_size"])
+    for k in range(g["traj"].shape[0]):
+        gg = torch.from_numpy(g["grad_g"][k]).to(gpu_device)
+        z_new, ll, gf_norm, gg_norm = net.langevin_step(z, gg, None, s)
+        assert abs(-ll.sum().item() - g["f_log_lkhd"][k]) <= 1e-5 * abs(g["f_log_lkhd"][k])
+        assert np.max(np.abs(z_new.cpu().numpy() - g["traj"][k])) <= 2e-5
+        ref_gf = np.linalg.norm(g["grad_f"][k], axis=1)
+        assert np.max(np.abs(gf_norm.cpu().numpy() - ref_gf) / ref_gf) <= 1e-5
+        ref_gg = np.linalg.norm(g["grad_g"][k], axis=1)
+        assert np.max(np.abs(gg_norm.cpu().numpy() - ref_gg) / ref_gg) <= 1e-5
+        z = z_new
+
+
+@pytest.mark.parametrize("nz,width,B", [(128, 64, 200), (100, 128, 37), (20, 10, 5)])
+def test_fused_step_with_noise_and_inplace(lsnf, gpu_device, nz, width, B):
+    p = O.init_params(nz, width, 5, seed=21)
+    net = make_net(lsnf, p, nz, width, 5, gpu_device)
+    gen = torch.Generator().manual_seed(3)
+    z = torch.randn(B, nz, generator=gen)
+    gg = torch.randn(B, nz, generator=gen)
+    noise = torch.randn(B, nz, generator=gen)
+    s = 0.1
+    ref, f_ref, gf_ref = O.langevin_prior_step(p, z, gg, s, noise)
+    ok = (O.relu_margin(p, z) > 2e-6)
+    zd = z.to(gpu_device)
+    z_new, ll, gf_norm, _ = net.langevin_step(zd, gg.to(gpu_device), noise.to(gpu_device), s)
+    assert torch.equal(zd.cpu(), z)                                   # not in place by default
+    assert (z_new.cpu() - ref)[ok].abs().max().item() <= 2e-5
+    assert abs(-ll.sum().item() - f_ref.item()) <= 1e-5 * abs(f_ref.item())
+    assert ((gf_norm.cpu() - gf_ref.norm(dim=1))[ok].abs() / gf_ref.norm(dim=1)[ok]).max().item() <= 1e-5
+    z_ip, _, _, _ = net.langevin_step(zd, gg.to(gpu_device), noise.to(gpu_device), s, inplace=True)
+    assert z_ip.data_ptr() == zd.data_ptr() and torch.equal(z_ip, z_new)
+    # no generator gradient, no noise
+    z3, _, _, gg3 = net.langevin_step(z.to(gpu_device), None, None, s)
+    ref3, _, _ = O.langevin_prior_step(p, z, None, s)
+    assert gg3 is None and (z3.cpu() - ref3)[ok].abs().max().item() <= 2e-5
+
+
+class ToyG(nn.Module):
+    """Stand-in generator for the harness test (the reference's _netG is out of scope): z -> 3x4x4 'image'."""
+    def __init__(self, nz):
+        super().__init__()
+        self.net = nn.Sequential(nn.ConvTranspose2d(nz, 8, 4, 1, 0), nn.LeakyReLU(0.2), nn.Conv2d(8, 3, 3, 1, 1), nn.Tanh())
+
+    def forward(self, z):
+        return self.net(z)
+
+
+def test_sampler_and_mle_step_harness_vs_oracle(lsnf, gpu_device):
+    """train.py:307-335 + 404-415 end to end (noise-free so that CPU and GPU can be compared)."""
+    nz, w, B, K, s, sigma = 20, 12, 9, 4, 0.1, 0.3
+    p = O.init_params(nz, w, 5, seed=8)
+    torch.manual_seed(0)
+    netG = ToyG(nz)
+    x = torch.tanh(torch.randn(B, 3, 4, 4))
+    z0 = torch.randn(B, nz, 1, 1)
+    # CPU: oracle flow + the same generator
+    mse = nn.MSELoss(reduction="sum")
+    z = z0.clone()
+    for _ in range(K):
+        zz = z.clone().requires_grad_(True)
+        g = 1.0 / (2.0 * sigma * sigma) * mse(netG(zz), x)
+        gg = torch.autograd.grad(g, zz)[0].view(B, nz)
+        znew, f_ref, gf = O.langevin_prior_step(p, z.view(B, nz), gg, s)
+        z = znew.view(B, nz, 1, 1)
+    # GPU: harness
+    net = make_net(lsnf, p, nz, w, 5, gpu_device)
+    zk, ggn, gfn, f = lsnf.langevin.sample_langevin_post_z_with_flow(
+        z0.to(gpu_device), x.to(gpu_device), netG.to(gpu_device), net, g_l_steps=K, g_l_step_size=s,
+        g_llhd_sigma=sigma, g_l_with_noise=False)
+    assert zk.shape == (B, nz, 1, 1)
+    assert (zk.cpu() - z).abs().max().item() <= 1e-4
+    assert abs(f.item() - f_ref.item()) <= 1e-4 * abs(f_ref.item())
+    assert abs(gfn.item() - gf.norm(dim=1).mean().item()) <= 1e-4 * gfn.item()
+    # with noise: runs, changes z, stays finite
+    zk2, _, _, _ = lsnf.langevin.sample_langevin_post_z_with_flow(
+        z0.to(gpu_device), x.to(gpu_device), netG, net, g_l_steps=2, g_l_step_size=s, g_llhd_sigma=sigma)
+    assert torch.isfinite(zk2).all() and not torch.equal(zk2, zk)
+    # flow MLE step: the loss equals the oracle's and goes down over a few Adam steps
+    opt = torch.optim.Adam(net.parameters(), lr=2e-3, betas=(0.5, 0.999))
+    _, _, ll_ref = O.flow_log_prob(p, z.view(B, nz))
+    l0 = lsnf.langevin.flow_mle_step(net, opt, zk, f_max_norm=100.0)
+    assert abs(l0.item() - (-ll_ref.mean().item())) <= 1e-4 * abs(ll_ref.mean().item())
+    for _ in range(5):
+        l1 = lsnf.langevin.flow_mle_step(net, opt, zk, f_max_norm=100.0)
+    assert l1.item() < l0.item()
