@@ -21,106 +21,142 @@ enum { P_AB = 0, P_ALOGS, P_W, P_W1, P_B1, P_LOGS1, P_W2, P_B2, P_LOGS2, P_W3, P
 __host__ __device__ static inline size_t scratch_block_doubles(int nz) { return (size_t)nz * nz + 8; }
 
 // ---------------------------------------------------------------------------------------------
-// (1) Gauss-Jordan: one workgroup per block, matrix resident in LDS as double [n][n+1].
+// (1) Gauss-Jordan with partial pivoting, float64, one workgroup (16 x 16 threads) per block.
+// The matrix lives in REGISTERS: thread (ry, cx) owns the 8 x 8 elements A[ry + 16*rr][cx + 16*jj].
+// Per column only the pivot column, the pivot row and the displaced row travel through LDS
+// (ping-pong buffers -> 2 barriers per column); every wave finds the pivot redundantly by shuffles.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lsnf_gj_kernel(LsnfParamPtrs pp, int nz, double* scratch) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int n = nz, ld = n + 1;         // odd leading dimension: column walks are bank-conflict free
-    double* A = sm;                       // n * ld   in-place inverse
-    double* prow = A + (size_t)n * ld;    // n   scaled pivot row of the current step
-    double* colv = prow + n;              // n   eliminated column of the current step
-    int* perm = (int*)(colv + n);         // n   pivot row chosen at step c
-    int* cmap = perm + n;                 // n   final column un-permutation
-    int* pivot = cmap + n;                // 1
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ry = tid >> 4, cx = tid & 15;            // 16 x 16 thread grid over the matrix
+    __shared__ double colbuf[2][128], rowp[2][128], rowc[2][128];
+    __shared__ double pivs[128];
+    __shared__ int perm[128], cinv[128];
+    const int n = nz;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int ry = tid >> 4, cx = tid & 15;
     const int blk = blockIdx.x;
     const float* W = pp.p[blk * 12 + P_W];
-    for (int r = ry; r < n; r += 16)
-        for (int j = cx; j < n; j += 16) A[r * ld + j] = (double)W[r * n + j];
-    __syncthreads();
-    double logabs = 0.0;                  // meaningful in thread 0
+    double a[8][8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int r = ry + 16 * rr, j = cx + 16 * jj;
+            a[rr][jj] = (r < n && j < n) ? (double)W[r * n + j] : ((r == j) ? 1.0 : 0.0);   // identity padding
+        }
     for (int c = 0; c < n; ++c) {
-        // (1) partial pivoting: wave 0 scans rows c..n-1 of column c, shuffle arg-max (ties -> lowest row)
-        if (wave == 0) {
-            double best = -1.0; int bi = c;
-            for (int r = c + lane; r < n; r += 64) {
-                const double v = fabs(A[r * ld + c]);
-                if (v > best) { best = v; bi = r; }
-            }
+        const int pb = c & 1, cjj = c >> 4, ccx = c & 15;
+        // (A) owners of column c publish it
+        if (cx == ccx) {
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const double ob = __shfl_xor(best, o, 64);
-                const int oi = __shfl_xor(bi, o, 64);
-                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-            }
-            if (lane == 0) { *pivot = bi; perm[c] = bi; }
-        }
-        __syncthreads();
-        const int p = *pivot;
-        // (2) read phase: rows c and p (to be exchanged) and column c
-        const double pv = A[p * ld + c];
-        double a_c = 0.0, a_p = 0.0, cv = 0.0;
-        if (tid < n) { a_c = A[c * ld + tid]; a_p = A[p * ld + tid]; }
-        else if (tid < 2 * n) { const int r = tid - n; cv = A[r * ld + c]; }
-        __syncthreads();
-        // (3) write phase: exchange, scale the pivot row (pivot slot becomes 1/pv), publish row / column
-        const double ipv = 1.0 / pv;
-        if (tid == 0) logabs += log(fabs(pv));
-        if (tid < n) {
-            const int j = tid;
-            const double pr = (j == c ? 1.0 : a_p) * ipv;
-            if (p != c) A[p * ld + j] = a_c;
-            A[c * ld + j] = pr;
-            prow[j] = pr;
-        } else if (tid < 2 * n) {
-            // multipliers of the elimination = column c AFTER the exchange: rows other than c, p keep theirs;
-            // row p now holds the old row c, whose entry old A[c][c] was read by the thread of r == c.
-            const int r = tid - n;
-            if (r == c) { if (p != c) colv[p] = cv; }
-            else if (r != p) colv[r] = cv;
-        }
-        __syncthreads();
-        // (4) eliminate column c from every row but c: 8 x 8 elements per thread, fully unrolled so that the
-        //     LDS reads of a thread are all in flight together (one workgroup per CU: latency, not bandwidth)
-        {
-            double pr[8];
+            for (int jj = 0; jj < 8; ++jj)
+                if (jj == cjj) {
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) { const int j = cx + 16 * jj; pr[jj] = (j < n) ? prow[j] : 0.0; }
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                const int r = ry + 16 * rr;
-                if (r < n && r != c) {
-                    const double f = colv[r];
-                    double av[8];
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) { const int j = cx + 16 * jj; av[jj] = (j < n && j != c) ? A[r * ld + j] : 0.0; }
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) { const int j = cx + 16 * jj; if (j < n) A[r * ld + j] = av[jj] - f * pr[jj]; }
+                    for (int rr = 0; rr < 8; ++rr) colbuf[pb][ry + 16 * rr] = a[rr][jj];
                 }
-            }
         }
         __syncthreads();
-    }
-    // undo the row interchanges as column interchanges (reverse order), composed into one map by thread 0
-    if (tid == 0) {
-        for (int j = 0; j < n; ++j) cmap[j] = j;
-        for (int c = n - 1; c >= 0; --c) {
-            const int p = perm[c];
-            if (p != c) { const int t = cmap[c]; cmap[c] = cmap[p]; cmap[p] = t; }
+        // (B) pivot row: arg max over r >= c of |A[r][c]| taken at float precision (any near-maximal pivot
+        //     is as good), packed with the row index into ONE 32-bit key so the wave reduction is a single
+        //     shuffle per round; every wave computes it redundantly (no broadcast barrier).
+        unsigned key = 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r = lane + 64 * q;
+            if (r >= c && r < n) {
+                const unsigned k = (__float_as_uint((float)fabs(colbuf[pb][r])) & 0xFFFFFF80u) | (unsigned)(127 - r);
+                key = k > key ? k : key;
+            }
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned ok = __shfl_xor(key, o, 64); key = ok > key ? ok : key; }
+        const int p = 127 - (int)(key & 127u);
+        const double pv = colbuf[pb][p];
+        const double old_cc = colbuf[pb][c];          // A[c][c] before the exchange (multiplier of row p afterwards)
+        const int prr = p >> 4, pry = p & 15, crr = c >> 4, cry = c & 15;
+        // (C) owners of rows p and c publish them
+        if (ry == pry) {
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr)
+                if (rr == prr) {
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) rowp[pb][cx + 16 * jj] = a[rr][jj];
+                }
+        }
+        if (ry == cry) {
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr)
+                if (rr == crr) {
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) rowc[pb][cx + 16 * jj] = a[rr][jj];
+                }
+        }
+        if (tid == 0) perm[c] = p;
+        __syncthreads();
+        // (D) exchange rows c <-> p, scale the pivot row (pivot slot -> 1/pv), eliminate column c elsewhere.
+        //     Generic rows: a -= f * pr with column c zeroed first (in-place inverse); rows c and p are then
+        //     overwritten by their owners -- keeps the 64-FMA body free of per-element selects.
+        const double ipv = 1.0 / pv;
+        if (tid == 0) pivs[c] = pv;
+        double pr[8], f[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) { const int j = cx + 16 * jj; pr[jj] = ((j == c) ? 1.0 : rowp[pb][j]) * ipv; }
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) f[rr] = colbuf[pb][ry + 16 * rr];
+        if (cx == ccx) {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)
+                if (jj == cjj) {
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr) a[rr][jj] = 0.0;
+                }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) a[rr][jj] = fma(-f[rr], pr[jj], a[rr][jj]);
+        if (ry == pry && p != c) {          // row p now holds the old row c, eliminated with multiplier old A[c][c]
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr)
+                if (rr == prr) {
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int j = cx + 16 * jj;
+                        a[rr][jj] = fma(-old_cc, pr[jj], (j == c) ? 0.0 : rowc[pb][j]);
+                    }
+                }
+        }
+        if (ry == cry) {                    // row c becomes the scaled pivot row
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr)
+                if (rr == crr) {
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) a[rr][jj] = pr[jj];
+                }
+        }
+    }
+    // undo the row interchanges as column interchanges: out[:, cinv[j]] = A[:, j]
+    __syncthreads();
+    if (tid == 0) {
+        int cmap[128];
+        for (int j = 0; j < 128; ++j) cmap[j] = j;
+        for (int c = n - 1; c >= 0; --c) { const int p = perm[c]; if (p != c) { const int t = cmap[c]; cmap[c] = cmap[p]; cmap[p] = t; } }
+        for (int j = 0; j < n; ++j) cinv[cmap[j]] = j;   // position j of the result holds work-column cmap[j]
     }
     __syncthreads();
     double* out = scratch + (size_t)blk * scratch_block_doubles(nz);
-    // after the swaps, position j holds what the un-swapped matrix has in column cmap[j]
-    for (int r = ry; r < n; r += 16)
-        for (int j = cx; j < n; j += 16) out[r * n + j] = A[r * ld + cmap[j]];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int r = ry + 16 * rr, j = cx + 16 * jj;
+            if (r < n && j < n) out[r * n + cinv[j]] = a[rr][jj];
+        }
     if (tid == 0) {
         const float* logs = pp.p[blk * 12 + P_ALOGS];
         // reference: torch.sum(logs * 3) in fp32 (model.py:264,273); each term logs*3 is rounded
         // to fp32 first, then summed -- we sum those fp32 terms in double and round once.
-        double s3 = 0.0;
-        for (int k = 0; k < n; ++k) s3 += (double)(logs[k] * 3.0f);
+        double s3 = 0.0, logabs = 0.0;
+        for (int k = 0; k < n; ++k) { s3 += (double)(logs[k] * 3.0f); logabs += log(fabs(pivs[k])); }
         out[(size_t)n * n + 0] = logabs;
         out[(size_t)n * n + 1] = s3;
     }
@@ -286,15 +322,7 @@ hipError_t lsnf_launch_prepare(const LsnfGeo& g, const float* const* params_host
     LsnfParamPtrs pp;
     for (int i = 0; i < g.depth * 12; ++i) pp.p[i] = params_host[i];
     for (int i = g.depth * 12; i < LSNF_MAX_DEPTH * 12; ++i) pp.p[i] = nullptr;
-    const int n = g.nz;
-    const size_t lds = sizeof(double) * ((size_t)n * (n + 1) + 2 * n) + sizeof(int) * (2 * n + 4);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)lsnf_gj_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(lsnf_gj_kernel, dim3(g.depth), dim3(256), lds, stream, pp, g.nz, (double*)scratch);
+    hipLaunchKernelGGL(lsnf_gj_kernel, dim3(g.depth), dim3(256), 0, stream, pp, g.nz, (double*)scratch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int per_block = g.fwd_const_floats + g.fwd_block_floats + g.inv_const_floats + g.inv_block_floats +

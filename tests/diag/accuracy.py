@@ -1,6 +1,6 @@
 """Error statistics of the HIP forward/backward vs float64 oracle, at the headline geometry (diagnostic)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, lsnf_amd
 from oracle import flow_oracle as O
 dev = torch.device("cuda:0")

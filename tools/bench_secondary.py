@@ -1,0 +1,59 @@
+"""Secondary measurements (SURVEY 8d 'secondary configs'): per-call latency of the flow path at the
+reference's training batch size (B=100) and throughput of the other kernels at B=65536.  No oracle here."""
+import json, os, sys, types
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import lsnf_amd
+
+dev = torch.device("cuda:0")
+
+def timeit(fn, n=200, warm=20):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3   # us
+
+def make(nz, w, seed=1):
+    hps = types.SimpleNamespace(f_n_levels=1, f_depth=5, f_flow_permutation=2, f_width=w, f_flow_coupling=1)
+    torch.manual_seed(seed); np.random.seed(seed)
+    net = lsnf_amd._netF(hps, nz=nz)
+    with torch.no_grad():
+        for n_, p_ in net.named_parameters():
+            if ".fc_zeros." in n_: p_.add_(0.05 * torch.randn_like(p_))
+    return net.to(dev)
+
+out = []
+for (tag, nz, w, B) in [("C2/C4 SVHN/CelebA nz=100 w=64 B=100", 100, 64, 100), ("C5 CelebA-HQ nz=100 w=128 B=100", 100, 128, 100),
+                        ("C3 geometry nz=128 w=64 B=100", 128, 64, 100), ("C3 nz=128 w=64 B=65536", 128, 64, 65536),
+                        ("C5 nz=100 w=128 B=65536", 100, 128, 65536)]:
+    net = make(nz, w)
+    z = torch.randn(B, nz, device=dev)
+    gg = torch.randn(B, nz, device=dev)
+    noise = torch.randn(B, nz, device=dev)
+    obj = torch.zeros(B, device=dev)
+    plan = net._plan()
+    n = 200 if B <= 1000 else 30
+    r = {"config": tag, "B": B}
+    r["forward_logprob_us"] = timeit(lambda: lsnf_amd.forward(plan, z), n)
+    z1, ld, ll, saved = lsnf_amd.forward(plan, z, save_for_backward=True)
+    r["forward_saving_us"] = timeit(lambda: lsnf_amd.forward(plan, z, save_for_backward=True), n)
+    r["backward_z_us"] = timeit(lambda: lsnf_amd.backward_z(plan, z1, saved, ll_scale=-1.0), n)
+    r["langevin_step_fwd_plus_fused_update_us"] = timeit(lambda: net.langevin_step(z, gg, noise, 0.1), n)
+    r["reverse_us"] = timeit(lambda: lsnf_amd.reverse(plan, z), n)
+    def mle():
+        net.zero_grad(set_to_none=True)
+        a, b, _ = net(z, objective=obj)
+        (-(-0.5 * (a ** 2).sum(1) + 1.8378770664093453 + b).mean()).backward()
+    r["mle_fwd_bwd_params_us"] = timeit(mle, max(10, n // 4), 5)
+    params = [p.detach() for p in net._param_list()]
+    r["prepare_us"] = timeit(lambda: lsnf_amd.prepare(params, nz, w, 5, plan=plan), 20, 3)
+    flop = 5 * (2 * nz * nz + 2 * (nz // 2 * w + w * w + w * nz)) * B
+    r["forward_tflops"] = flop / r["forward_logprob_us"] / 1e6
+    r["backward_z_tflops_counting_1.5x_fwd"] = 1.5 * flop / r["backward_z_us"] / 1e6
+    out.append(r)
+    print(json.dumps(r), flush=True)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/secondary.json", "w"), indent=1)
