@@ -5,8 +5,9 @@ geometry nz=128 f_width=64 f_depth=5, B=65536 rows PER GPU of synthetic z (BASEL
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the hot path over one batch: the fused forward launch (z -> z1, logdet, ll),
-the on-device sum of ll (train.py:320) and -- for N > 1 -- the single RCCL all-reduce of that sum.
+A step = one pass of the hot path over one batch: the fused forward launch (z -> z1, logdet, ll, and
+sum_b ll accumulated in the kernel's epilogue, train.py:320) and -- for N > 1 -- the single RCCL all-reduce
+of that sum.
 z, the prepared weights and all outputs are resident in HBM when the timed region starts.
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   "roofline":     the forward kernel's algorithmic FLOP/s (HIP-event timed, kernel-only loop) against
@@ -121,9 +122,12 @@ def main():
     ll = torch.empty(B_PER_GPU, device=dev)
     from lsnf_amd import parallel
 
+    stats = lsnf_amd.flow.new_stats(dev)
+
     def step():
-        lsnf_amd.forward(plan, z, out=(z1, logdet, ll))
-        return parallel.reduce_sum_ll(ll)   # on-device sum (train.py:320) + the single all-reduce when N > 1
+        # forward + log-prob; sum_b ll (train.py:320) is accumulated inside the kernel; N > 1: the single all-reduce
+        lsnf_amd.forward(plan, z, out=(z1, logdet, ll), stats=stats)
+        return parallel.reduce_stats_inplace(stats)
 
     def fence():
         if dist is not None:

@@ -88,12 +88,17 @@ int lsnf_prepare(const float* const* params_host, int nz, int width, int depth, 
  *   logdet_out(B)       objective + sum of the blocks' log|det J|
  *   ll_out    (B) or NULL: -0.5*sum_j z_out^2 + log(2*pi) + logdet_out  (train.py:317-319)
  *   z_saved   NULL, or ((n_blocks-1), B, nz): outputs of all but the last block, kept for
- *             lsnf_backward_z / lsnf_backward_params.                                     */
+ *             lsnf_backward_z / lsnf_backward_params.
+ *   stats     NULL, or 8 doubles (device, 8-byte aligned) that the caller zero-initialises ONCE:
+ *             after the launch stats[4] = sum_b ll_b (train.py:320), stats[5] = sum_b logdet_b,
+ *             stats[6] = B.  Summed inside the kernel (fp64 atomics, one pair per workgroup; the last
+ *             workgroup publishes and re-arms stats[0..2], which are internal).  One stats buffer
+ *             must not be shared by launches on different streams.                            */
 int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling,
                  int first_block, int n_blocks, int B,
                  const float* z_in, const float* objective,
                  float* z_out, float* logdet_out, float* ll_out, float* z_saved,
-                 void* stream);
+                 double* stats, void* stream);
 
 /* ---- reverse: replaces `_netF.forward(z, objective, reverse=True)` (model.py:484-498,
  * block inverse model.py:424-456).  Functional: inputs are not modified (the reference

@@ -24,7 +24,7 @@ _SIGNATURES = {
     "lsnf_prepare_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
     "lsnf_prepare": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "lsnf_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lsnf_reverse": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int,
                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lsnf_backward_z": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -14,7 +14,7 @@ hipError_t lsnf_launch_prepare(const LsnfGeo& g, const float* const* params_host
 size_t lsnf_prep_scratch_bytes(int nz, int depth);
 hipError_t lsnf_launch_forward(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                const float* z_in, const float* objective, float* z_out, float* logdet_out,
-                               float* ll_out, float* z_saved, int vec4, hipStream_t stream);
+                               float* ll_out, float* z_saved, double* stats, int vec4, hipStream_t stream);
 hipError_t lsnf_launch_reverse(const LsnfGeo& g, const float* plan, int B, const float* z_in, const float* objective,
                                float* z_out, float* objective_out, int vec4, hipStream_t stream);
 hipError_t lsnf_launch_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
@@ -96,11 +96,15 @@ int lsnf_prepare(const float* const* params_host, int nz, int width, int depth, 
 
 int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, int first_block, int n_blocks, int B,
                  const float* z_in, const float* objective, float* z_out, float* logdet_out, float* ll_out,
-                 float* z_saved, void* stream) {
+                 float* z_saved, double* stats, void* stream) {
     LsnfGeo g;
     if (int rc = geo_or_fail(&g, nz, width, depth, coupling)) return rc;
     if (B < 0 || B > (1 << 28)) return fail(LSNF_E_ARG, "lsnf_forward: B=%d out of range", B);
-    if (B == 0) return LSNF_OK;   // empty batch: nothing to do (pointers of empty tensors may be NULL)
+    if (B == 0) {   // empty batch: nothing to do (pointers of empty tensors may be NULL)
+        if (stats && hipMemsetAsync(stats + 4, 0, 3 * sizeof(double), (hipStream_t)stream) != hipSuccess)
+            return fail(LSNF_E_HIP, "lsnf_forward: hipMemsetAsync(stats) failed");
+        return LSNF_OK;
+    }
     if (!plan || !z_in || !z_out || !logdet_out) return fail(LSNF_E_ARG, "lsnf_forward: NULL argument");
     if (first_block < 0 || n_blocks < 1 || first_block + n_blocks > depth)
         return fail(LSNF_E_ARG, "lsnf_forward: blocks [%d,%d) outside [0,%d)", first_block, first_block + n_blocks, depth);
@@ -109,8 +113,9 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
         return fail(LSNF_E_ARG, "lsnf_forward: tensors must be 4-byte aligned");
     if (B == 0) return LSNF_OK;
     const int vec4 = (g.half % 4 == 0) && aligned16(z_in) && aligned16(z_out) && (z_saved == nullptr || aligned16(z_saved));
+    if (stats && (reinterpret_cast<uintptr_t>(stats) & 7u)) return fail(LSNF_E_ARG, "lsnf_forward: stats must be 8-byte aligned");
     hipError_t e = lsnf_launch_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
-                                       z_saved, vec4, (hipStream_t)stream);
+                                       z_saved, stats, vec4, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "lsnf_forward launch");
     return LSNF_OK;
 }

@@ -42,6 +42,7 @@ struct FwdArgs {
     float* z_saved;
     int B, nz, half, n_blocks, vec4;
     int stagger_mode, stagger_count;   // see lsnf_stagger() in lsnf_device.h
+    double* stats;                     // NULL or 8 doubles: see lsnf_forward (in-kernel sum of ll / logdet over the batch)
     unsigned long long* stamps;        // LSNF_STAMPS diagnostic build only: [grid][4 waves][64] shader-clock stamps
 };
 
@@ -169,6 +170,36 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_fwd_kernel(const FwdA
             if (a.ll_out) a.ll_out[sample] = (-0.5f * ss + 1.8378770664093453f) + ell;
         }
     }
+    if (a.stats) {   // kernel-uniform: batch sums of ll and logdet, one pair of fp64 atomics per workgroup
+        float sl = (live && h == 0) ? ((-0.5f * ss + 1.8378770664093453f) + ell) : 0.0f;
+        float sd = (live && h == 0) ? ell : 0.0f;
+        double dl = (double)sl, dd = (double)sd;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { dl += __shfl_xor(dl, o, 64); dd += __shfl_xor(dd, o, 64); }
+        __syncthreads();                               // the weight buffers are dead: reuse their first bytes
+        double* red = reinterpret_cast<double*>(buf0);
+        if (lane == 0) { red[2 * wave] = dl; red[2 * wave + 1] = dd; }
+        __syncthreads();
+        if (tid == 0) {
+            double tl = 0.0, td = 0.0;
+            for (int w = 0; w < LSNF_WG_WAVES; ++w) { tl += red[2 * w]; td += red[2 * w + 1]; }
+            // Returning atomics: their values come back only after the adds have been performed at the memory
+            // side, and the ticket increment is made to depend on them -- ordering without an L2 write-back fence
+            // (a release fence here would flush this workgroup's freshly written z_out lines: +2..6 us per WG).
+            const double r0 = atomicAdd(&a.stats[0], tl);
+            const double r1 = atomicAdd(&a.stats[1], td);
+            unsigned long long inc = 1ull;
+            asm volatile("" : "+v"(inc) : "v"(r0), "v"(r1));
+            unsigned long long* ticket = reinterpret_cast<unsigned long long*>(&a.stats[2]);
+            const unsigned long long t = atomicAdd(ticket, inc);
+            if (t == (unsigned long long)gridDim.x - 1) {   // last workgroup: publish and re-arm for the next launch
+                const double fl = atomicAdd(&a.stats[0], 0.0), fd = atomicAdd(&a.stats[1], 0.0);
+                a.stats[4] = fl; a.stats[5] = fd; a.stats[6] = (double)a.B;
+                atomicAdd(&a.stats[0], -fl); atomicAdd(&a.stats[1], -fd);
+                atomicExch(ticket, 0ull);
+            }
+        }
+    }
     LSNF_STAMP(40);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     LSNF_STAMP(41);
@@ -199,8 +230,9 @@ extern "C" unsigned long long* lsnf_debug_stamps(void) { return g_lsnf_stamps; }
 // host-side dispatcher (called from lsnf_api.hip)
 hipError_t lsnf_launch_forward(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                const float* z_in, const float* objective, float* z_out, float* logdet_out,
-                               float* ll_out, float* z_saved, int vec4, hipStream_t stream) {
+                               float* ll_out, float* z_saved, double* stats, int vec4, hipStream_t stream) {
     FwdArgs a;
+    a.stats = stats;
     a.consts = plan + g.off_fwd_const + (size_t)first_block * g.fwd_const_floats;
     a.panels = plan + g.off_fwd_panels + (size_t)first_block * g.fwd_block_floats;
     a.z_in = z_in; a.objective = objective; a.z_out = z_out; a.logdet_out = logdet_out; a.ll_out = ll_out;

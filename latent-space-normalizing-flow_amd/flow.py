@@ -122,9 +122,12 @@ def params_from_state_dict(sd, depth: int, device=None) -> List[torch.Tensor]:
 
 def forward(plan: FlowPlan, z: torch.Tensor, objective: Optional[torch.Tensor] = None, *,
             first_block: int = 0, n_blocks: Optional[int] = None, want_ll: bool = True,
-            save_for_backward: bool = False, out: Optional[Tuple[torch.Tensor, ...]] = None):
+            save_for_backward: bool = False, out: Optional[Tuple[torch.Tensor, ...]] = None,
+            stats: Optional[torch.Tensor] = None):
     """One launch: blocks [first_block, first_block+n_blocks) on (B, nz) rows.
-    Returns (z_out, logdet, ll or None, z_saved or None).  model.py:473-483 + train.py:317-319."""
+    Returns (z_out, logdet, ll or None, z_saved or None).  model.py:473-483 + train.py:317-319.
+    stats: optional buffer from `new_stats()`; afterwards stats[4] = sum ll, stats[5] = sum logdet, stats[6] = B
+    (summed inside the kernel -- no separate reduction launch)."""
     lib = _lib.load()
     _need_cuda(z, "z")
     if z.dim() != 2 or z.shape[1] != plan.nz:
@@ -147,9 +150,14 @@ def forward(plan: FlowPlan, z: torch.Tensor, objective: Optional[torch.Tensor] =
     with torch.cuda.device(z.device):
         rc = lib.lsnf_forward(_ptr(plan.buf), plan.nz, plan.width, plan.depth, plan.coupling, first_block, n_blocks, B,
                               _ptr(z), _ptr(objective), _ptr(z_out), _ptr(logdet), _ptr(ll), _ptr(saved),
-                              _stream_ptr(z.device))
+                              _ptr(stats), _stream_ptr(z.device))
     _lib.check(rc, "lsnf_forward")
     return z_out, logdet, ll, saved
+
+
+def new_stats(device) -> torch.Tensor:
+    """Zero-initialised 8-double accumulator for `forward(..., stats=)` (one per stream)."""
+    return torch.zeros(8, dtype=torch.float64, device=device)
 
 
 def reverse(plan: FlowPlan, z: torch.Tensor, objective: Optional[torch.Tensor] = None):

@@ -59,6 +59,16 @@ def reduce_sum_ll(ll: torch.Tensor, group=None) -> torch.Tensor:
     return s
 
 
+def reduce_stats_inplace(stats: torch.Tensor, group=None) -> torch.Tensor:
+    """`stats` = the buffer filled by `flow.forward(..., stats=)`: all-reduces its public part
+    [sum ll, sum logdet, rows] over the ranks (the single collective of the path) and returns that view.
+    With one rank it is a no-op: the sums were already produced inside the forward kernel."""
+    pub = stats[4:7]
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(pub, op=dist.ReduceOp.SUM, group=group)
+    return pub
+
+
 def sharded_log_prob(evaluate: Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]],
                      z_local: torch.Tensor, group=None):
     """evaluate(z_local) -> (z1, logdet, ll) on this rank's rows (product: `_netF.log_prob`).

@@ -132,3 +132,20 @@ def test_errors_are_loud(lsnf, gpu_device):
         lsnf.flow.alloc_plan(130, 64, 5, 1, gpu_device)            # geometry out of range
     z1, ld, ll, _ = lsnf.forward(plan, torch.zeros(0, 8, device=gpu_device))   # empty batch is legal
     assert z1.shape == (0, 8) and ll.shape == (0,)
+
+
+@pytest.mark.parametrize("B", [1, 100, 129, 5000])
+def test_in_kernel_batch_sums(lsnf, gpu_device, B):
+    """stats: sum ll / sum logdet / rows accumulated by the kernel itself, re-armed for every launch."""
+    p = O.init_params(128, 64, 5, seed=2)
+    plan = lsnf.prepare(lsnf.params_from_state_dict(p, 5, gpu_device), 128, 64, 5)
+    stats = lsnf.flow.new_stats(gpu_device)
+    for rep in range(3):                       # repeated launches: the accumulator must come back to zero
+        z = torch.randn(B, 128, device=gpu_device)
+        z1, ld, ll, _ = lsnf.forward(plan, z, stats=stats)
+        s = stats.cpu()
+        assert abs(s[4].item() - ll.double().sum().item()) <= 1e-9 * abs(ll.double().sum().item()) + 1e-9
+        assert abs(s[5].item() - ld.double().sum().item()) <= 1e-9 * abs(ld.double().sum().item()) + 1e-9
+        assert s[6].item() == B and s[0].item() == 0.0 and s[1].item() == 0.0 and s[2].item() == 0.0
+    lsnf.forward(plan, torch.zeros(0, 128, device=gpu_device), stats=stats)
+    assert stats.cpu()[4:7].tolist() == [0.0, 0.0, 0.0]
