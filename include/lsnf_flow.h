@@ -58,6 +58,11 @@ extern "C" {
 int lsnf_abi_version(void);
 const char* lsnf_last_error(void);
 
+/* Tuning knob: batches of at most `rows` rows run on the small-batch (latency) kernels, larger ones on the
+ * throughput kernels; both compute the same function (results agree to fp32 rounding, not bit for bit).
+ * rows < 0 only queries.  Returns the previous value (default 16384, or the LSNF_SMALL_MAX environment variable). */
+int lsnf_set_small_batch_max(int rows);
+
 /* Device query: writes the gfx arch name (e.g. "gfx950") of device `device`; LSNF_E_NODEVICE
  * if there is none.  Only call that touches the device without doing work. */
 int lsnf_device_arch(int device, char* buf, size_t buflen);

@@ -5,6 +5,10 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
+#ifndef LSNF_SMALL_MAX_DEFAULT
+#define LSNF_SMALL_MAX_DEFAULT 16384
+#endif
 
 #include "../../include/lsnf_flow.h"
 #include "lsnf_layout.h"
@@ -15,12 +19,18 @@ size_t lsnf_prep_scratch_bytes(int nz, int depth);
 hipError_t lsnf_launch_forward(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                float* ll_out, float* z_saved, double* stats, int vec4, hipStream_t stream);
+hipError_t lsnf_launch_small_forward(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
+                                     const float* z_in, const float* objective, float* z_out, float* logdet_out,
+                                     float* ll_out, float* z_saved, double* stats, int vec4, hipStream_t stream);
 hipError_t lsnf_launch_reverse(const LsnfGeo& g, const float* plan, int B, const float* z_in, const float* objective,
                                float* z_out, float* objective_out, int vec4, hipStream_t stream);
 hipError_t lsnf_launch_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
                                   const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
                                   float* g_z_in, float* dump, float* gl_total, int vec4, hipStream_t stream,
                                   const LsnfLangevinArgs* lv = nullptr);
+hipError_t lsnf_launch_small_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
+                                        const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale, float* g_z_in,
+                                        int vec4, hipStream_t stream, const LsnfLangevinArgs* lv);
 hipError_t lsnf_launch_backward_params(const LsnfGeo& g, const float* plan, const float* const* params_host,
                                        float* const* grads_host, int B, const float* z_in, const float* z_out,
                                        const float* z_saved, const float* g_z1, const float* g_logdet, int ll_mode,
@@ -42,6 +52,13 @@ int hip_fail(hipError_t e, const char* what) {
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
 
+// rows at or below which the small-batch kernels are used (LSNF_SMALL_MAX overrides; 0 disables them)
+int g_small_max = -1;
+int small_batch_max() {
+    if (g_small_max < 0) { const char* e = getenv("LSNF_SMALL_MAX"); g_small_max = e ? atoi(e) : LSNF_SMALL_MAX_DEFAULT; }
+    return g_small_max;
+}
+
 int geo_or_fail(LsnfGeo* g, int nz, int width, int depth, int coupling) {
     if (lsnf_geo_init(g, nz, width, depth, coupling))
         return fail(LSNF_E_GEOMETRY, "unsupported geometry nz=%d width=%d depth=%d coupling=%d "
@@ -54,6 +71,12 @@ int geo_or_fail(LsnfGeo* g, int nz, int width, int depth, int coupling) {
 extern "C" {
 
 int lsnf_abi_version(void) { return LSNF_ABI_VERSION; }
+
+int lsnf_set_small_batch_max(int rows) {
+    const int prev = small_batch_max();
+    if (rows >= 0) g_small_max = rows;
+    return prev;
+}
 const char* lsnf_last_error(void) { return g_err; }
 
 int lsnf_device_arch(int device, char* buf, size_t buflen) {
@@ -114,8 +137,13 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
     if (B == 0) return LSNF_OK;
     const int vec4 = (g.half % 4 == 0) && aligned16(z_in) && aligned16(z_out) && (z_saved == nullptr || aligned16(z_saved));
     if (stats && (reinterpret_cast<uintptr_t>(stats) & 7u)) return fail(LSNF_E_ARG, "lsnf_forward: stats must be 8-byte aligned");
-    hipError_t e = lsnf_launch_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
-                                       z_saved, stats, vec4, (hipStream_t)stream);
+    // batch-size dispatch: latency kernel (32 rows per workgroup, stages split over the 4 waves) below the
+    // crossover, throughput kernel (128 rows per workgroup, weights shared through LDS) above it
+    hipError_t e = (B <= small_batch_max())
+        ? lsnf_launch_small_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
+                                    z_saved, stats, vec4, (hipStream_t)stream)
+        : lsnf_launch_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
+                              z_saved, stats, vec4, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "lsnf_forward launch");
     return LSNF_OK;
 }
@@ -151,8 +179,11 @@ int lsnf_backward_z(const float* plan, int nz, int width, int depth, int couplin
     if (B == 0) return LSNF_OK;
     const int vec4 = (g.half % 4 == 0) && aligned16(z_out) && aligned16(g_z_in) && (z_saved == nullptr || aligned16(z_saved)) &&
                      (g_z1 == nullptr || aligned16(g_z1));
-    hipError_t e = lsnf_launch_backward_z(g, plan, B, z_out, z_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, nullptr,
-                                          nullptr, vec4, (hipStream_t)stream);
+    hipError_t e = (B <= small_batch_max())
+        ? lsnf_launch_small_backward_z(g, plan, B, z_out, z_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, vec4,
+                                       (hipStream_t)stream, nullptr)
+        : lsnf_launch_backward_z(g, plan, B, z_out, z_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, nullptr,
+                                 nullptr, vec4, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "lsnf_backward_z launch");
     return LSNF_OK;
 }
@@ -171,8 +202,11 @@ int lsnf_langevin_step(const float* plan, int nz, int width, int depth, int coup
         return fail(LSNF_E_ARG, "lsnf_langevin_step: tensors must be 4-byte aligned");
     const int vec4 = (g.half % 4 == 0) && aligned16(z_out) && (z_saved == nullptr || aligned16(z_saved));
     LsnfLangevinArgs lv = {z_cur, grad_g, noise, z_new, gf_norm, gg_norm, step_size};
-    hipError_t e = lsnf_launch_backward_z(g, plan, B, z_out, z_saved, nullptr, nullptr, /*ll_mode=*/1, /*ll_scale=*/-1.0f,
-                                          nullptr, nullptr, nullptr, vec4, (hipStream_t)stream, &lv);
+    hipError_t e = (B <= small_batch_max())
+        ? lsnf_launch_small_backward_z(g, plan, B, z_out, z_saved, nullptr, nullptr, /*ll_mode=*/1, /*ll_scale=*/-1.0f,
+                                       nullptr, vec4, (hipStream_t)stream, &lv)
+        : lsnf_launch_backward_z(g, plan, B, z_out, z_saved, nullptr, nullptr, /*ll_mode=*/1, /*ll_scale=*/-1.0f,
+                                 nullptr, nullptr, nullptr, vec4, (hipStream_t)stream, &lv);
     if (e != hipSuccess) return hip_fail(e, "lsnf_langevin_step launch");
     return LSNF_OK;
 }

@@ -1,0 +1,110 @@
+// lsnf_small.h -- building blocks of the SMALL-BATCH kernels (lsnf_small_fwd.hip, lsnf_small_bwd.hip).
+//
+// The throughput kernels give each wave 32 samples and ALL features: 2560 dependent-chain MFMAs per wave and
+// forward, so a batch of <= 128 rows runs on one CU for ~90 us.  Here a workgroup owns only 32 samples and its
+// 4 waves split every GEMM stage between them -- by output tile (NT >= 4) or by output tile x K range
+// (NT = 2: K split in two, NT = 1: in four) -- so the serial MFMA chain per stage is 16..64 instead of
+// 64..256.  Stage outputs travel wave -> LDS -> wave as accumulator-layout tiles (partial sums when K is split;
+// the consumer adds them and applies the activation), which is exactly the B-operand layout the next stage
+// needs.  Weights are not shared between waves any more, so they skip LDS: each wave loads the fragments of
+// ITS panel slice straight from L2 into VGPRs (lane-linear 16 B per lane), one stage ahead of their use.
+#pragma once
+#include "lsnf_device.h"
+
+#define LSNF_SMALL_SAMPLES 32
+#define LSNF_TILE_FLOATS 1024   // one activation tile in LDS: [g(4)][lane(64)][4 floats]
+
+// how a stage of NT output tiles and KT k-tiles is spread over 4 waves (FORCE_KS > 0 overrides the K split)
+template <int NT, int KT, int FORCE_KS = 0>
+struct SmallSplit {
+    static constexpr int AUTO = (NT >= 4) ? 1 : (NT == 2 ? (KT >= 2 ? 2 : 1) : (NT == 1 ? (KT >= 4 ? 4 : (KT >= 2 ? 2 : 1)) : 1));
+    static constexpr int KS = FORCE_KS > 0 ? FORCE_KS : AUTO;
+    static constexpr int KTL = KT / KS;                  // k-tiles per unit
+    static constexpr int UNITS = NT * KS;                // units of work (<= 4: one per wave)
+    static_assert(KT % KS == 0, "K split must divide KT");
+    static_assert(UNITS <= 4, "one unit per wave");
+};
+
+// tile in accumulator layout <-> LDS tile
+__device__ __forceinline__ void small_store_tile(float* lds_tile, const f32x16& a, int lane) {
+    f32x4* p = reinterpret_cast<f32x4*>(lds_tile) + lane;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { f32x4 v = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]}; p[g * 64] = v; }
+}
+__device__ __forceinline__ f32x16 small_load_tile(const float* lds_tile, int lane) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(lds_tile) + lane;
+    f32x16 a;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { const f32x4 v = p[g * 64]; a[4 * g] = v[0]; a[4 * g + 1] = v[1]; a[4 * g + 2] = v[2]; a[4 * g + 3] = v[3]; }
+    return a;
+}
+// sum of KS partial tiles (consecutive in LDS), optional relu
+template <int KS, bool RELU>
+__device__ __forceinline__ f32x16 small_gather_tile(const float* lds_tiles, int lane) {
+    f32x16 a = small_load_tile(lds_tiles, lane);
+#pragma unroll
+    for (int s = 1; s < KS; ++s) {
+        const f32x16 b = small_load_tile(lds_tiles + s * LSNF_TILE_FLOATS, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] += b[r];
+    }
+    if (RELU) a = lsnf_relu16(a);
+    return a;
+}
+// a[r] = (gate[r] > 0) ? a[r] : 0      (relu backward, model.py:307-308)
+__device__ __forceinline__ f32x16 small_gate16(f32x16 a, const f32x16& gate) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = gate[r] > 0.0f ? a[r] : 0.0f;
+    return a;
+}
+
+// weight fragments of one unit (KTL k-tiles of one n-tile) held in registers
+template <int KTL>
+struct SmallFrags { f32x4 w[KTL * 4]; };
+
+// One GEMM stage out[nt] = init(nt) + W_nt^T in, NT output tiles, KT input tiles, spread over the 4 waves.
+// Outputs are written to LDS as NT*KS (partial) tiles, index nt*KS + ks; the caller's `in(kt)` functor returns
+// input tile kt in accumulator layout (it gathers / activates / gates whatever the producer left in LDS).
+template <int NT_, int KT_, int FORCE_KS = 0>
+struct SmallStage {
+    static constexpr int NT = NT_, KT = KT_;
+    using Split = SmallSplit<NT_, KT_, FORCE_KS>;
+    static constexpr int KS = Split::KS, KTL = Split::KTL, UNITS = Split::UNITS;
+    static constexpr int OUT_TILES = NT_ * Split::KS;
+
+    // issue the global loads of this wave's weight fragments (panels: n-tile major, KT k-tiles each)
+    __device__ static __forceinline__ SmallFrags<KTL> fetch(const float* gpanels, int wave, int lane) {
+        SmallFrags<KTL> f;
+        if (wave < UNITS) {
+            const int nt = wave / KS, ks = wave % KS;
+            const f32x4* g = reinterpret_cast<const f32x4*>(gpanels + ((size_t)nt * KT + ks * KTL) * LSNF_FRAG_FLOATS) + lane;
+#pragma unroll
+            for (int i = 0; i < KTL * 4; ++i) f.w[i] = g[i * 64];
+        } else {
+#pragma unroll
+            for (int i = 0; i < KTL * 4; ++i) f.w[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        return f;
+    }
+
+    template <class InFn, class InitFn>
+    __device__ static __forceinline__ void run(const SmallFrags<KTL>& fr, float* out_lds, int wave, int lane, InFn&& in,
+                                               InitFn&& init) {
+        if (wave >= UNITS) return;                       // wave-uniform
+        const int nt = wave / KS, ks = wave % KS;
+        f32x16 acc = (ks == 0) ? init(nt) : lsnf_zero16();
+#pragma unroll
+        for (int k = 0; k < KTL; ++k) {
+            const f32x16 x = in(ks * KTL + k);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 w = fr.w[k * 4 + g];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], x[4 * g + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], x[4 * g + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], x[4 * g + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], x[4 * g + 3], acc, 0, 0, 0);
+            }
+        }
+        small_store_tile(out_lds + (size_t)(nt * KS + ks) * LSNF_TILE_FLOATS, acc, lane);
+    }
+};

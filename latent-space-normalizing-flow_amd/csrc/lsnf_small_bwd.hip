@@ -1,0 +1,254 @@
+// lsnf_small_bwd.hip -- latency-oriented backward w.r.t. z (+ fused Langevin update) for small / medium batches.
+// Same math and ABI entry points (lsnf_backward_z, lsnf_langevin_step dispatch on B) as lsnf_bwd.hip, which replaces
+// autograd of train.py:316-329; work decomposition of lsnf_small.h (32 samples per workgroup, stages split over
+// the 4 waves, tiles exchanged through LDS, weights straight from L2 one stage ahead).
+//
+// Per block, last to first (g = dL/d[z1|z2'] lives in LDS tiles GX, block output y = [v1|y2] in Y):
+//   R2,R3,R4 : recompute h1, h2, [t;p] from v1                       (forward panels S2..S4)
+//   CB       : s = sigmoid(p); g_t = g_v2 = g_y2*s ; g_p = (1-s)(g_y2*y2 + g_l)
+//   B4       : g_h2 = [W3s W3p][g_t;g_p]        B3 : g_h1 = W2'(g_h2 * [h2>0])
+//   B2       : g_v1 = g_v1 + W1'(g_h1 * [h1>0]) B1 : g_x  = Wa [g_v1; g_v2]
+#include "lsnf_small.h"
+
+namespace {
+
+template <int HT_, int WT_>
+struct SmallBwdCfg {
+    static constexpr int HT = HT_, WT = WT_, NZT = 2 * HT_;
+    static constexpr int P1 = NZT, P2 = WT, P3 = WT, P4 = 2 * HT, NP = P1 + P2 + P3 + P4;
+    static constexpr int FWD_BLOCK = LSNF_FRAG_FLOATS * (NZT * NZT + WT * HT + WT * WT + 2 * HT * WT);
+    static constexpr int FWD_CONST = 32 * NP + 32;
+    static constexpr int OFF_S2 = LSNF_FRAG_FLOATS * NZT * NZT;
+    static constexpr int OFF_S3 = OFF_S2 + LSNF_FRAG_FLOATS * WT * HT;
+    static constexpr int OFF_S4 = OFF_S3 + LSNF_FRAG_FLOATS * WT * WT;
+    static constexpr int BWD_BLOCK = LSNF_FRAG_FLOATS * (WT * 2 * HT + WT * WT + HT * WT + NZT * NZT);
+    static constexpr int OFF_B4 = 0;
+    static constexpr int OFF_B3 = OFF_B4 + LSNF_FRAG_FLOATS * WT * 2 * HT;
+    static constexpr int OFF_B2 = OFF_B3 + LSNF_FRAG_FLOATS * WT * WT;
+    static constexpr int OFF_B1 = OFF_B2 + LSNF_FRAG_FLOATS * HT * WT;
+    static constexpr int CONST_USED = 32 * (P2 + P3 + P4);     // S2, S3, S4 biases
+    using R2 = SmallStage<WT, HT>;
+    using R3 = SmallStage<WT, WT>;
+    using R4 = SmallStage<2 * HT, WT>;
+    using B4 = SmallStage<WT, 2 * HT>;
+    using B3 = SmallStage<WT, WT>;
+    using B2 = SmallStage<HT, WT, 1>;                          // unsplit: writes final g_v1 tiles
+    using B1 = SmallStage<NZT, NZT, 1>;                        // unsplit: writes final g_x tiles
+    // LDS map (tiles)
+    static constexpr int T_GX = 0;                             // 2 x NZT ping-pong running gradient
+    static constexpr int T_Y = T_GX + 2 * NZT;                 // NZT block output
+    static constexpr int T_H1 = T_Y + NZT;
+    static constexpr int T_H2 = T_H1 + R2::OUT_TILES;
+    static constexpr int T_TP = T_H2 + R3::OUT_TILES;          // [t;p] partials; dead after CB -> reused for g_h2 partials
+    static constexpr int T_GH2 = T_TP;
+    static constexpr int N_TP = R4::OUT_TILES > B4::OUT_TILES ? R4::OUT_TILES : B4::OUT_TILES;
+    static constexpr int T_GTP = T_TP + N_TP;                  // 2HT: g_t tiles then g_p tiles (final); dead after B4 -> g_h1 partials
+    static constexpr int T_GH1 = T_GTP;
+    static constexpr int N_GTP = 2 * HT > B3::OUT_TILES ? 2 * HT : B3::OUT_TILES;
+    static constexpr int T_GV = T_GTP + N_GTP;                 // NZT: [g_v1 ; g_v2] (final)
+    static constexpr int T_END = T_GV + NZT;
+    static constexpr int AUX_FLOATS = 64 * (2 * NZT + 2);
+};
+
+struct SmallBwdArgs {
+    const float* fwd_consts; const float* fwd_panels; const float* bwd_panels;
+    const float* z_out; const float* z_saved; const float* g_z1; const float* g_logdet;
+    float* g_z_in;
+    const float* z_cur; const float* grad_g; const float* noise; float* z_new; float* gf_norm; float* gg_norm;
+    float step, ll_scale;
+    int ll_mode, B, nz, half, depth, vec4;
+};
+
+template <class C>
+__global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(const SmallBwdArgs a) {
+    constexpr int HT = C::HT, NZT = C::NZT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tiles = smem;
+    float* aux = smem + (size_t)C::T_END * LSNF_TILE_FLOATS;
+    float* cst = aux + C::AUX_FLOATS;                                // depth * CONST_USED
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, m = lane & 31, h = lane >> 5;
+    const bool vec4 = a.vec4 != 0;
+    auto T = [&](int t) { return tiles + (size_t)t * LSNF_TILE_FLOATS; };
+
+    const int last = a.depth - 1;
+    auto f2 = C::R2::fetch(a.fwd_panels + (size_t)last * C::FWD_BLOCK + C::OFF_S2, wave, lane);
+    for (int i = tid; i < a.depth * C::CONST_USED; i += LSNF_WG_THREADS) {
+        const int blk = i / C::CONST_USED, r = i % C::CONST_USED;
+        cst[i] = a.fwd_consts[blk * C::FWD_CONST + 32 * C::P1 + r];
+    }
+    const long sample = (long)blockIdx.x * LSNF_SMALL_SAMPLES + m;
+    const bool live = sample < a.B;
+    const long row = live ? sample : (long)a.B - 1;
+
+    // upstream gradient -> GX[parity of last block], block output of the last block -> Y
+    float gl;
+    if (a.ll_mode) gl = a.ll_scale; else gl = a.g_logdet ? a.g_logdet[row] : 0.0f;
+    if (wave < NZT) {
+        const f32x16 y = lsnf_load_tile<HT>(wave, a.z_out + row * (long)a.nz, a.half, h, vec4);
+        small_store_tile(T(C::T_Y + wave), y, lane);
+        f32x16 g;
+        if (a.ll_mode) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[r] = -a.ll_scale * y[r];     // dL/dz1 = -ll_scale * z1 (train.py:317-320)
+        } else if (a.g_z1) g = lsnf_load_tile<HT>(wave, a.g_z1 + row * (long)a.nz, a.half, h, vec4);
+        else g = lsnf_zero16();
+        small_store_tile(T(C::T_GX + (last & 1) * NZT + wave), g, lane);
+    }
+    __syncthreads();
+
+    for (int blk = last; blk >= 0; --blk) {
+        const float* cb = cst + blk * C::CONST_USED;
+        const float* gf = a.fwd_panels + (size_t)blk * C::FWD_BLOCK;
+        const float* gb = a.bwd_panels + (size_t)blk * C::BWD_BLOCK;
+        float* GX = T(C::T_GX + (blk & 1) * NZT);
+        float* GXn = T(C::T_GX + ((blk + 1) & 1) * NZT);           // becomes GX of block blk-1
+        float* Y = T(C::T_Y); float* H1 = T(C::T_H1); float* H2 = T(C::T_H2); float* TP = T(C::T_TP);
+        float* GTP = T(C::T_GTP); float* GH2 = T(C::T_GH2); float* GH1 = T(C::T_GH1); float* GV = T(C::T_GV);
+        auto tile = [&](const float* base, int t) { return small_load_tile(base + (size_t)t * LSNF_TILE_FLOATS, lane); };
+
+        // ---- R2: h1 = W1'^T v1 + c1 ----
+        auto f3 = C::R3::fetch(gf + C::OFF_S3, wave, lane);
+        C::R2::run(f2, H1, wave, lane, [&](int kt) { return tile(Y, kt); }, [&](int nt) { return lsnf_bias_init(cb + 32 * nt, h); });
+        __syncthreads();
+        // ---- R3: h2 = W2'^T relu(h1) + c2 ----
+        auto f4 = C::R4::fetch(gf + C::OFF_S4, wave, lane);
+        C::R3::run(f3, H2, wave, lane,
+                   [&](int kt) { return small_gather_tile<C::R2::KS, true>(H1 + (size_t)kt * C::R2::KS * LSNF_TILE_FLOATS, lane); },
+                   [&](int nt) { return lsnf_bias_init(cb + 32 * (C::P2 + nt), h); });
+        __syncthreads();
+        // ---- R4: [t; p] ----
+        auto fb4 = C::B4::fetch(gb + C::OFF_B4, wave, lane);
+        C::R4::run(f4, TP, wave, lane,
+                   [&](int kt) { return small_gather_tile<C::R3::KS, true>(H2 + (size_t)kt * C::R3::KS * LSNF_TILE_FLOATS, lane); },
+                   [&](int nt) { return lsnf_bias_init(cb + 32 * (C::P2 + C::P3 + nt), h); });
+        __syncthreads();
+        // ---- CB: coupling backward on waves 0..HT-1 ----
+        if (wave < HT) {
+            const int j = wave;
+            const f32x16 p = small_gather_tile<C::R4::KS, false>(TP + (size_t)(HT + j) * C::R4::KS * LSNF_TILE_FLOATS, lane);
+            const f32x16 gy2 = tile(GX, HT + j), y2 = tile(Y, HT + j);
+            f32x16 gt, gp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sig, lsig;
+                lsnf_sigmoid_logsig(p[r], sig, lsig);
+                gt[r] = gy2[r] * sig;
+                gp[r] = (1.0f - sig) * (gy2[r] * y2[r] + gl);
+            }
+            small_store_tile(GTP + (size_t)j * LSNF_TILE_FLOATS, gt, lane);
+            small_store_tile(GTP + (size_t)(HT + j) * LSNF_TILE_FLOATS, gp, lane);
+            small_store_tile(GV + (size_t)(HT + j) * LSNF_TILE_FLOATS, gt, lane);
+        }
+        __syncthreads();
+        // ---- B4: g_h2 = [W3s W3p][g_t; g_p] ----
+        auto fb3 = C::B3::fetch(gb + C::OFF_B3, wave, lane);
+        C::B4::run(fb4, GH2, wave, lane, [&](int kt) { return tile(GTP, kt); }, [&](int) { return lsnf_zero16(); });
+        __syncthreads();
+        // ---- B3: g_h1 = W2' (g_h2 gated by h2 > 0) ----
+        auto fb2 = C::B2::fetch(gb + C::OFF_B2, wave, lane);
+        C::B3::run(fb3, GH1, wave, lane,
+                   [&](int kt) {
+                       return small_gate16(small_gather_tile<C::B4::KS, false>(GH2 + (size_t)kt * C::B4::KS * LSNF_TILE_FLOATS, lane),
+                                           small_gather_tile<C::R3::KS, false>(H2 + (size_t)kt * C::R3::KS * LSNF_TILE_FLOATS, lane));
+                   },
+                   [&](int) { return lsnf_zero16(); });
+        __syncthreads();
+        // ---- B2: g_v1 = g_v1(direct) + W1' (g_h1 gated by h1 > 0) -> GV[0..HT) ----
+        auto fb1 = C::B1::fetch(gb + C::OFF_B1, wave, lane);
+        // next block's output tile: global load issued here, parked in registers until Y is free
+        f32x16 ynext = lsnf_zero16();
+        if (blk > 0 && wave < NZT)
+            ynext = lsnf_load_tile<HT>(wave, a.z_saved + ((size_t)(blk - 1) * a.B + row) * a.nz, a.half, h, vec4);
+        C::B2::run(fb2, GV, wave, lane,
+                   [&](int kt) {
+                       return small_gate16(small_gather_tile<C::B3::KS, false>(GH1 + (size_t)kt * C::B3::KS * LSNF_TILE_FLOATS, lane),
+                                           small_gather_tile<C::R2::KS, false>(H1 + (size_t)kt * C::R2::KS * LSNF_TILE_FLOATS, lane));
+                   },
+                   [&](int nt) { return tile(GX, nt); });
+        __syncthreads();
+        // ---- B1: g_x = Wa [g_v1; g_v2] -> GXn ----
+        if (blk > 0) f2 = C::R2::fetch(a.fwd_panels + (size_t)(blk - 1) * C::FWD_BLOCK + C::OFF_S2, wave, lane);
+        C::B1::run(fb1, GXn, wave, lane, [&](int kt) { return tile(GV, kt); }, [&](int) { return lsnf_zero16(); });
+        if (blk > 0 && wave < NZT) small_store_tile(Y + (size_t)wave * LSNF_TILE_FLOATS, ynext, lane);   // Y's readers are done
+        __syncthreads();
+    }
+
+    // ---- outputs: g_z_in and / or the fused Langevin update (train.py:324-329), one tile per wave ----
+    float* GXf = T(C::T_GX + (1 & 1) * NZT);   // block 0 wrote GXn = GX[(0+1)&1]
+    float gf2 = 0.0f, gg2 = 0.0f;
+    if (wave < NZT) {
+        const f32x16 g = small_load_tile(GXf + (size_t)wave * LSNF_TILE_FLOATS, lane);
+        if (live && a.g_z_in) lsnf_store_tile<HT>(wave, g, a.g_z_in + sample * (long)a.nz, a.half, h, vec4);
+        if (a.z_new) {
+            const float coef = 0.5f * a.step * a.step;
+            const f32x16 zc = lsnf_load_tile<HT>(wave, a.z_cur + row * (long)a.nz, a.half, h, false);
+            f32x16 gs = g;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gf2 += g[r] * g[r];
+            if (a.grad_g) {
+                const f32x16 gg = lsnf_load_tile<HT>(wave, a.grad_g + row * (long)a.nz, a.half, h, false);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { gg2 += gg[r] * gg[r]; gs[r] = gg[r] + g[r]; }
+            }
+            f32x16 zn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zn[r] = zc[r] - coef * gs[r];
+            if (a.noise) {
+                const f32x16 nv = lsnf_load_tile<HT>(wave, a.noise + row * (long)a.nz, a.half, h, false);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zn[r] = zn[r] + a.step * nv[r];
+            }
+            if (live) lsnf_store_tile<HT>(wave, zn, a.z_new + sample * (long)a.nz, a.half, h, false);
+        }
+    }
+    if (a.z_new && (a.gf_norm || a.gg_norm)) {      // kernel-uniform
+        if (wave < NZT) { aux[64 * wave + lane] = gf2; aux[64 * (NZT + wave) + lane] = gg2; }
+        __syncthreads();
+        if (wave == 0) {
+            float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+            for (int t = 0; t < NZT; ++t) { s1 += aux[64 * t + lane]; s2 += aux[64 * (NZT + t) + lane]; }
+            s1 = lsnf_pair_sum(s1); s2 = lsnf_pair_sum(s2);
+            if (live && h == 0) {
+                if (a.gf_norm) a.gf_norm[sample] = sqrtf(s1);
+                if (a.gg_norm) a.gg_norm[sample] = sqrtf(s2);
+            }
+        }
+    }
+}
+
+template <class C>
+hipError_t launch_small_bwd(const SmallBwdArgs& a, hipStream_t stream) {
+    const size_t lds = ((size_t)C::T_END * LSNF_TILE_FLOATS + C::AUX_FLOATS + (size_t)a.depth * C::CONST_USED) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto kern = lsnf_small_bwd_kernel<C>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)((a.B + LSNF_SMALL_SAMPLES - 1) / LSNF_SMALL_SAMPLES);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(LSNF_WG_THREADS), lds, stream, a);
+    return hipGetLastError();
+}
+}  // namespace
+
+// returns hipErrorInvalidValue when the geometry's LDS footprint does not fit (caller falls back to lsnf_bwd.hip)
+hipError_t lsnf_launch_small_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
+                                        const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale, float* g_z_in,
+                                        int vec4, hipStream_t stream, const LsnfLangevinArgs* lv) {
+    SmallBwdArgs a;
+    a.fwd_consts = plan + g.off_fwd_const; a.fwd_panels = plan + g.off_fwd_panels; a.bwd_panels = plan + g.off_bwd_panels;
+    a.z_out = z_out; a.z_saved = z_saved; a.g_z1 = g_z1; a.g_logdet = g_logdet; a.g_z_in = g_z_in;
+    a.z_cur = nullptr; a.grad_g = nullptr; a.noise = nullptr; a.z_new = nullptr; a.gf_norm = nullptr; a.gg_norm = nullptr; a.step = 0.f;
+    if (lv) { a.z_cur = lv->z_cur; a.grad_g = lv->grad_g; a.noise = lv->noise; a.z_new = lv->z_new; a.gf_norm = lv->gf_norm;
+              a.gg_norm = lv->gg_norm; a.step = lv->step; }
+    a.ll_scale = ll_scale; a.ll_mode = ll_mode; a.B = B; a.nz = g.nz; a.half = g.half; a.depth = g.depth; a.vec4 = vec4;
+    if (g.HT == 1 && g.WT == 1) return launch_small_bwd<SmallBwdCfg<1, 1>>(a, stream);
+    if (g.HT == 2 && g.WT == 2) return launch_small_bwd<SmallBwdCfg<2, 2>>(a, stream);
+    if (g.HT == 2 && g.WT == 4) return launch_small_bwd<SmallBwdCfg<2, 4>>(a, stream);
+    return hipErrorInvalidValue;
+}

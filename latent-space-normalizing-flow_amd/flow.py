@@ -155,6 +155,11 @@ def forward(plan: FlowPlan, z: torch.Tensor, objective: Optional[torch.Tensor] =
     return z_out, logdet, ll, saved
 
 
+def set_small_batch_max(rows: int) -> int:
+    """Batches <= rows use the small-batch (latency) kernels; returns the previous threshold (rows < 0: query)."""
+    return _lib.load().lsnf_set_small_batch_max(int(rows))
+
+
 def new_stats(device) -> torch.Tensor:
     """Zero-initialised 8-double accumulator for `forward(..., stats=)` (one per stream)."""
     return torch.zeros(8, dtype=torch.float64, device=device)

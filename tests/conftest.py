@@ -43,3 +43,12 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(params=["latency-kernels", "throughput-kernels"])
+def kernels(request):
+    """Every parity test runs on both kernel families (normally selected by batch size, lsnf_set_small_batch_max)."""
+    import lsnf_amd
+    prev = lsnf_amd.flow.set_small_batch_max(1 << 30 if request.param == "latency-kernels" else 0)
+    yield request.param
+    lsnf_amd.flow.set_small_batch_max(prev)

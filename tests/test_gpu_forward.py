@@ -39,7 +39,7 @@ def test_prepare_logdet_and_inverse(lsnf, gpu_device, name):
 
 
 @pytest.mark.parametrize("name", golden_names())
-def test_forward_matches_reference_golden(lsnf, gpu_device, name):
+def test_forward_matches_reference_golden(lsnf, kernels, gpu_device, name):
     p, g = load_golden(name)
     plan, nz, w, d = _plan(lsnf, p, g, gpu_device)
     z = torch.from_numpy(g["z"]).to(gpu_device)
@@ -56,7 +56,7 @@ def test_forward_matches_reference_golden(lsnf, gpu_device, name):
 
 
 @pytest.mark.parametrize("name", golden_names())
-def test_per_block_launches_match(lsnf, gpu_device, name):
+def test_per_block_launches_match(lsnf, kernels, gpu_device, name):
     """One launch per coupling block (first_block=i, n_blocks=1), chained through HBM."""
     p, g = load_golden(name)
     plan, nz, w, d = _plan(lsnf, p, g, gpu_device)
@@ -70,7 +70,7 @@ def test_per_block_launches_match(lsnf, gpu_device, name):
         assert np.max(np.abs(ld.cpu().numpy() - refl) / np.maximum(np.abs(refl), 1.0)) <= LL_REL
 
 
-def test_saved_activations_are_block_outputs(lsnf, gpu_device):
+def test_saved_activations_are_block_outputs(lsnf, kernels, gpu_device):
     p, g = load_golden("c3_nz128_w64_B200")
     plan, nz, w, d = _plan(lsnf, p, g, gpu_device)
     z = torch.from_numpy(g["z"]).to(gpu_device)
@@ -82,7 +82,7 @@ def test_saved_activations_are_block_outputs(lsnf, gpu_device):
 
 @pytest.mark.parametrize("nz,width,B", [(128, 64, 1), (128, 64, 33), (128, 64, 129), (100, 64, 300), (64, 32, 97),
                                         (20, 10, 130), (100, 128, 257), (2, 1, 5), (126, 127, 77)])
-def test_forward_vs_oracle_ragged(lsnf, gpu_device, nz, width, B):
+def test_forward_vs_oracle_ragged(lsnf, kernels, gpu_device, nz, width, B):
     """Seeded synthetic weights / inputs at ragged sizes (partial waves, partial workgroups, odd nz/2)."""
     depth = 5
     p = O.init_params(nz, width, depth, seed=nz + width)
@@ -106,9 +106,15 @@ def test_full_size_properties(lsnf, gpu_device):
     plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
     z = torch.randn(B, nz, generator=torch.Generator().manual_seed(1234))
     zd = z.to(gpu_device)
-    z1, ld, ll, _ = lsnf.forward(plan, zd)
-    z1s, lds, lls, _ = lsnf.forward(plan, zd[:4096].contiguous())
-    assert torch.equal(z1[:4096], z1s) and torch.equal(ll[:4096], lls) and torch.equal(ld[:4096], lds)
+    prev = lsnf.flow.set_small_batch_max(8192)
+    z1, ld, ll, _ = lsnf.forward(plan, zd)                                   # throughput kernel
+    z1s, lds, lls, _ = lsnf.forward(plan, zd[:16384].contiguous())           # throughput kernel, fewer rows
+    assert torch.equal(z1[:16384], z1s) and torch.equal(ll[:16384], lls) and torch.equal(ld[:16384], lds)
+    z1q, ldq, llq, _ = lsnf.forward(plan, zd[:4096].contiguous())            # latency kernel: same function, fp32 rounding apart
+    assert (z1[:4096] - z1q).abs().max().item() <= 2e-5 and ((ll[:4096] - llq).abs() / llq.abs()).max().item() <= 2e-6
+    z1p, ldp, llp, _ = lsnf.forward(plan, zd[:1024].contiguous())            # latency kernel is row independent bit for bit too
+    assert torch.equal(z1q[:1024], z1p) and torch.equal(llq[:1024], llp)
+    lsnf.flow.set_small_batch_max(prev)
     idx = torch.arange(0, B, 127)
     z1r, ldr, llr = O.flow_log_prob(p, z[idx])
     assert ((ll.cpu()[idx] - llr).abs() / llr.abs()).max().item() <= LL_REL
@@ -135,7 +141,7 @@ def test_errors_are_loud(lsnf, gpu_device):
 
 
 @pytest.mark.parametrize("B", [1, 100, 129, 5000])
-def test_in_kernel_batch_sums(lsnf, gpu_device, B):
+def test_in_kernel_batch_sums(lsnf, kernels, gpu_device, B):
     """stats: sum ll / sum logdet / rows accumulated by the kernel itself, re-armed for every launch."""
     p = O.init_params(128, 64, 5, seed=2)
     plan = lsnf.prepare(lsnf.params_from_state_dict(p, 5, gpu_device), 128, 64, 5)

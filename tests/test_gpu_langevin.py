@@ -26,7 +26,7 @@ def make_net(lsnf, p, nz, w, d, dev):
     return net.to(dev)
 
 
-def test_fused_step_replays_reference_trajectory(lsnf, gpu_device):
+def test_fused_step_replays_reference_trajectory(lsnf, kernels, gpu_device):
     """The noise-free K=3 trajectory captured from the reference (its own _netG gradients replayed)."""
     p, g = load_golden("langevin_nz100_w64_B16_K3")
     net = make_net(lsnf, p, 100, 64, 5, gpu_device)
@@ -45,7 +45,7 @@ def test_fused_step_replays_reference_trajectory(lsnf, gpu_device):
 
 
 @pytest.mark.parametrize("nz,width,B", [(128, 64, 200), (100, 128, 37), (20, 10, 5)])
-def test_fused_step_with_noise_and_inplace(lsnf, gpu_device, nz, width, B):
+def test_fused_step_with_noise_and_inplace(lsnf, kernels, gpu_device, nz, width, B):
     p = O.init_params(nz, width, 5, seed=21)
     net = make_net(lsnf, p, nz, width, 5, gpu_device)
     gen = torch.Generator().manual_seed(3)

@@ -35,7 +35,7 @@ def ll_of(z1, logdet):
 
 
 @pytest.mark.parametrize("name", golden_names())
-def test_langevin_call_site(lsnf, gpu_device, name):
+def test_langevin_call_site(lsnf, kernels, gpu_device, name):
     """train.py:316-323 verbatim on the module: forward, log-prob in torch ops, autograd.grad w.r.t. z."""
     p, g = load_golden(name)
     net, nz = make_net(lsnf, p, g, gpu_device)

@@ -48,7 +48,7 @@ def test_roundtrip_forward_reverse(lsnf, gpu_device, name):
 
 
 @pytest.mark.parametrize("name", golden_names())
-def test_grad_z_matches_reference_golden(lsnf, gpu_device, name):
+def test_grad_z_matches_reference_golden(lsnf, kernels, gpu_device, name):
     """d(-sum ll)/dz (train.py:320-323), fused ll_mode."""
     p, g = load_golden(name)
     plan = _plan(lsnf, p, g, gpu_device)
@@ -66,7 +66,7 @@ def test_grad_z_matches_reference_golden(lsnf, gpu_device, name):
 
 
 @pytest.mark.parametrize("nz,width,B", [(128, 64, 130), (100, 64, 77), (100, 128, 50), (20, 10, 33), (2, 1, 3)])
-def test_backward_general_upstream_vs_oracle(lsnf, gpu_device, nz, width, B):
+def test_backward_general_upstream_vs_oracle(lsnf, kernels, gpu_device, nz, width, B):
     """Arbitrary upstream gradients (g_z1, g_logdet) against autograd over the oracle."""
     depth = 5
     p = O.init_params(nz, width, depth, seed=3 * nz + width)
@@ -89,7 +89,7 @@ def test_backward_general_upstream_vs_oracle(lsnf, gpu_device, nz, width, B):
     assert ((got2 - ref2)[ok].norm() / ref2[ok].norm()).item() <= 1e-5
 
 
-def test_langevin_trajectory_golden(lsnf, gpu_device):
+def test_langevin_trajectory_golden(lsnf, kernels, gpu_device):
     """Noise-free K-step Langevin trajectory captured from the reference (train.py:311-326) with the
     generator's gradient replayed from the fixture: pins the caller-side update around the flow."""
     p, g = load_golden("langevin_nz100_w64_B16_K3")

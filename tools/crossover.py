@@ -1,0 +1,28 @@
+"""Latency of the forward (and backward) at several batch sizes on both kernel families -> crossover."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, bench, lsnf_amd
+dev = torch.device("cuda:0")
+w = [t.to(dev) for t in bench.synth_weights(1)]
+plan = lsnf_amd.prepare(w, 128, 64, 5)
+def timeit(fn, n):
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
+for B in (32, 100, 256, 1024, 4096, 8192, 16384, 32768, 65536):
+    z = torch.randn(B, 128, device=dev)
+    res = []
+    for name, thr in (("latency", 1 << 30), ("throughput", 0)):
+        lsnf_amd.flow.set_small_batch_max(thr)
+        if which == "fwd":
+            t = timeit(lambda: lsnf_amd.forward(plan, z), 100)
+        else:
+            z1, ld, ll, sv = lsnf_amd.forward(plan, z, save_for_backward=True)
+            t = timeit(lambda: lsnf_amd.backward_z(plan, z1, sv, ll_scale=-1.0), 100)
+        res.append(t)
+    print(f"{which} B={B:6d}  latency-kernel {res[0]:8.1f} us   throughput-kernel {res[1]:8.1f} us")
