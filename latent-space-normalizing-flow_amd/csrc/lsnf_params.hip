@@ -110,9 +110,14 @@ __global__ __launch_bounds__(256) void lsnf_unfold_kernel(LsnfParamPtrs pp, Lsnf
     float* const* Gp = &gp.p[blk * 12];
     const float* winv = winv_all + (size_t)blk * nz * nz;
     const double Gtot = (double)gl_total[0];
+    // exp(3*logs) of the four log-scale vectors, once (float64)
+    __shared__ double ea[128], e1v[128], e2v[128], e3v[128];
+    for (int k = tid; k < nz; k += 256) { ea[k] = exp((double)(P[P_ALOGS][k] * 3.0f)); e3v[k] = exp((double)(P[P_LOGS3][k] * 3.0f)); }
+    for (int k = tid; k < w; k += 256) { e1v[k] = exp((double)(P[P_LOGS1][k] * 3.0f)); e2v[k] = exp((double)(P[P_LOGS2][k] * 3.0f)); }
+    __syncthreads();
     // ---- actnorm + 1x1 conv:  Wa = diag(e) W, ca = (b*e) W, const = 3*sum(s) + log|det W|
     for (int k = tid; k < nz; k += 256) {
-        const double e = exp((double)(P[P_ALOGS][k] * 3.0f)), b = (double)P[P_AB][k];
+        const double e = ea[k], b = (double)P[P_AB][k];
         double t1 = 0.0, t2 = 0.0;
         for (int n = 0; n < nz; ++n) {
             const double wkn = (double)P[P_W][k * nz + n];
@@ -125,15 +130,16 @@ __global__ __launch_bounds__(256) void lsnf_unfold_kernel(LsnfParamPtrs pp, Lsnf
     if (Gp[P_W])
         for (int idx = tid; idx < nz * nz; idx += 256) {
             const int k = idx / nz, n = idx % nz;
-            const double e = exp((double)(P[P_ALOGS][k] * 3.0f)), b = (double)P[P_AB][k];
+            const double e = ea[k], b = (double)P[P_AB][k];
             Gp[P_W][idx] = (float)(e * (double)F[fl.dWa + idx] + b * e * (double)F[fl.dca + n] + Gtot * (double)winv[n * nz + k]);
         }
     // ---- fc_1 / fc_2:  W' = W diag(e), c = b*e
     for (int layer = 0; layer < 2; ++layer) {
         const int iw = layer ? P_W2 : P_W1, ib = layer ? P_B2 : P_B1, il = layer ? P_LOGS2 : P_LOGS1;
         const int rows = layer ? w : half, oW = layer ? fl.dW2 : fl.dW1, oc = layer ? fl.dc2 : fl.dc1;
+        const double* ev = layer ? e2v : e1v;
         for (int n = tid; n < w; n += 256) {
-            const double e = exp((double)(P[il][n] * 3.0f)), b = (double)P[ib][n], dc = (double)F[oc + n];
+            const double e = ev[n], b = (double)P[ib][n], dc = (double)F[oc + n];
             double u = 0.0;
             for (int k = 0; k < rows; ++k) u += (double)P[iw][k * w + n] * (double)F[oW + k * w + n];
             if (Gp[ib]) Gp[ib][n] = (float)(dc * e);
@@ -142,14 +148,14 @@ __global__ __launch_bounds__(256) void lsnf_unfold_kernel(LsnfParamPtrs pp, Lsnf
         if (Gp[iw])
             for (int idx = tid; idx < rows * w; idx += 256) {
                 const int n = idx % w;
-                Gp[iw][idx] = (float)((double)F[oW + idx] * exp((double)(P[il][n] * 3.0f)));
+                Gp[iw][idx] = (float)((double)F[oW + idx] * ev[n]);
             }
     }
     // ---- fc_zeros: column c = 2f + which (shift / pre-sigmoid interleaved, model.py:411-413)
     for (int c = tid; c < nz; c += 256) {
         const int f = c >> 1, which = c & 1;
         const int oW = which ? fl.dW3p : fl.dW3s, oc = which ? fl.dc3p : fl.dc3s;
-        const double e = exp((double)(P[P_LOGS3][c] * 3.0f)), b = (double)P[P_B3][c], dc = (double)F[oc + f];
+        const double e = e3v[c], b = (double)P[P_B3][c], dc = (double)F[oc + f];
         double u = 0.0;
         for (int k = 0; k < w; ++k) u += (double)P[P_W3][k * nz + c] * (double)F[oW + k * half + f];
         if (Gp[P_B3]) Gp[P_B3][c] = (float)(dc * e);
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(256) void lsnf_unfold_kernel(LsnfParamPtrs pp, Lsnf
         for (int idx = tid; idx < w * nz; idx += 256) {
             const int k = idx / nz, c = idx % nz, f = c >> 1, which = c & 1;
             const int oW = which ? fl.dW3p : fl.dW3s;
-            Gp[P_W3][idx] = (float)((double)F[oW + k * half + f] * exp((double)(P[P_LOGS3][c] * 3.0f)));
+            Gp[P_W3][idx] = (float)((double)F[oW + k * half + f] * e3v[c]);
         }
 }
 }  // namespace
