@@ -94,8 +94,8 @@ def cpu_baseline(weights, budget_s=14.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=300)   # the chip needs ~50 ms of sustained load to reach its steady clock
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -122,14 +122,17 @@ def main():
     ll = torch.empty(B_PER_GPU, device=dev)
     from lsnf_amd import parallel
 
-    stats = lsnf_amd.flow.new_stats(dev)
+    reducer = parallel.PipelinedStatsReducer(dev)
 
     def step():
-        # forward + log-prob; sum_b ll (train.py:320) is accumulated inside the kernel; N > 1: the single all-reduce
+        # forward + log-prob; sum_b ll (train.py:320) is accumulated inside the kernel.  N > 1: the single all-reduce
+        # of that sum is submitted asynchronously and overlaps the NEXT step's kernel (two stats buffers alternate).
+        stats = reducer.next_buffer()
         lsnf_amd.forward(plan, z, out=(z1, logdet, ll), stats=stats)
-        return parallel.reduce_stats_inplace(stats)
+        reducer.submit(stats)
 
     def fence():
+        reducer.finish()            # every outstanding all-reduce is complete before the clock is read
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()

@@ -58,6 +58,9 @@ static inline void lsnf_stagger_config(int*, int*) {}
 // Each wave-instruction moves 1 KiB (64 lanes x 16 B), destination = wave-uniform base + lane*16.
 template <int KT>
 __device__ __forceinline__ void lsnf_issue_panel(const float* __restrict__ gsrc, float* lbuf, int wave, int lane) {
+#ifdef LSNF_ABLATE_DMA   // timing diagnostic only (wrong numbers): prices the L2 -> LDS weight stream and its power
+    return;
+#endif
 #pragma unroll
     for (int s = 0; s < KT; ++s) {
         const int seg = s * LSNF_WG_WAVES + wave;  // 1 KiB segment index
@@ -270,10 +273,12 @@ __device__ __forceinline__ void lsnf_panel_mma2(f32x16& acc0, f32x16& acc1, cons
     for (int H = 0; H < 2 * KT; ++H) {                       // half k-tiles: groups 2H, 2H+1
         const int kt = H >> 1, g0 = (H & 1) * 2;
         f32x4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+#ifndef LSNF_ABLATE_LDSREAD   // timing diagnostic only (wrong numbers): prices the LDS fragment reads / their power
         if (H + 1 < 2 * KT) {
             na0 = wp[(2 * H + 2) * 64]; na1 = wp[(2 * H + 3) * 64];
             nb0 = wp[T1 + (2 * H + 2) * 64]; nb1 = wp[T1 + (2 * H + 3) * 64];
         }
+#endif
 #define LSNF_MFMA2(WA, WB, G)                                                                         \
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(WA[0], in[kt][4 * (G) + 0], acc0, 0, 0, 0);       \
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(WB[0], in[kt][4 * (G) + 0], acc1, 0, 0, 0);       \

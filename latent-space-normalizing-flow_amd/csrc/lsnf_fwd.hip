@@ -99,7 +99,11 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_fwd_kernel(const FwdA
 #endif
 
     LSNF_STAMP(1);
+    const int slot = __builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1));   // HW wave slot parity
+    if (a.stagger_mode == 4) { if (slot) __builtin_amdgcn_s_setprio(1); }
     for (int blk = 0; blk < a.n_blocks; ++blk) {
+        // experimental fairness knob (speed only): the two co-resident workgroups alternate issue priority per block
+        if (a.stagger_mode == 5) { if ((blk ^ slot) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         const float* cb = cst + blk * C::CONST_FLOATS;
         const float* gblk = a.panels + (size_t)blk * C::BLOCK_FLOATS;
         const bool more = blk + 1 < a.n_blocks;

@@ -69,6 +69,57 @@ def reduce_stats_inplace(stats: torch.Tensor, group=None) -> torch.Tensor:
     return pub
 
 
+class PipelinedStatsReducer:
+    """Hides the latency of the one collective of the path behind the next evaluation.
+
+    The all-reduce of [sum ll, sum logdet, rows] is ~20 us of pure latency on 8 GPUs (24 bytes); nothing in the
+    Langevin loop consumes the reduced value before the next flow evaluation starts (it is a logged diagnostic,
+    train.py:320,332), so step i's all-reduce runs on the communication stream WHILE step i+1's forward kernel
+    runs on the compute stream.  Two stats buffers alternate; a buffer is handed out again only after the
+    collective that reads it has been waited for (a stream-level wait for RCCL, no host sync).
+
+        red = PipelinedStatsReducer(device)
+        for i in range(K):
+            stats = red.next_buffer()               # waits (stream-level) for the collective of step i-2
+            flow.forward(plan, z, stats=stats)
+            red.submit(stats)                       # async all-reduce of stats[4:7]
+        totals = red.finish()                       # public part of the last submitted buffer, reduced
+    """
+
+    def __init__(self, device, group=None, make_buffer=None):
+        mk = make_buffer or (lambda: torch.zeros(8, dtype=torch.float64, device=device))
+        self.bufs = [mk(), mk()]
+        self.work = [None, None]
+        self.i = 0
+        self.group = group
+        self.last = None
+
+    def _multi(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def next_buffer(self) -> torch.Tensor:
+        k = self.i & 1
+        if self.work[k] is not None:
+            self.work[k].wait()
+            self.work[k] = None
+        return self.bufs[k]
+
+    def submit(self, stats: torch.Tensor) -> None:
+        k = self.i & 1
+        assert stats is self.bufs[k], "submit() must receive the buffer handed out by next_buffer()"
+        if self._multi():
+            self.work[k] = dist.all_reduce(stats[4:7], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.last = k
+        self.i += 1
+
+    def finish(self) -> Optional[torch.Tensor]:
+        for k in (0, 1):
+            if self.work[k] is not None:
+                self.work[k].wait()
+                self.work[k] = None
+        return None if self.last is None else self.bufs[self.last][4:7]
+
+
 def sharded_log_prob(evaluate: Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]],
                      z_local: torch.Tensor, group=None):
     """evaluate(z_local) -> (z1, logdet, ll) on this rank's rows (product: `_netF.log_prob`).

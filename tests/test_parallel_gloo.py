@@ -33,6 +33,16 @@ def _worker(rank, world, port, out):
     lo, hi = P.shard_bounds(B, world, rank)
     # (1) sharded log-prob + the one collective
     z1, ld, ll, stats = P.sharded_log_prob(lambda t: O.flow_log_prob(p, t), z[lo:hi])
+    # (1b) the pipelined reducer (double-buffered async all-reduce) used by bench.py
+    red = P.PipelinedStatsReducer(torch.device("cpu"))
+    piped = []
+    for it in range(5):
+        st = red.next_buffer()
+        if it >= 2:                                   # the buffer coming back holds step it-2, fully reduced
+            piped.append(st[4:7].clone())
+        st[4], st[5], st[6] = float(ll.sum()) * (it + 1), float(ld.sum()), float(ll.numel())
+        red.submit(st)
+    fin = red.finish().clone()
     # (2) broadcast: rank 1 starts from different weights and must end up with rank 0's
     q = O.init_params(NZ, WIDTH, DEPTH, seed=4 + rank)
     live = [q[k] for k in sorted(q) if O.is_live_param(k)]
@@ -47,7 +57,7 @@ def _worker(rank, world, port, out):
     dead = torch.nn.Parameter(torch.zeros(3))            # a parameter without grad must be skipped
     n = P.allreduce_gradients(leaves + [dead], average=False)
     if rank == 0:
-        out.put({"stats": stats.tolist(), "same": same, "n": n, "ll": ll.tolist(), "lo_hi": (lo, hi),
+        out.put({"stats": stats.tolist(), "same": same, "n": n, "piped": [p_.tolist() for p_ in piped], "fin": fin.tolist(), "ll": ll.tolist(), "lo_hi": (lo, hi),
                  "grads": {k: l.grad.numpy().copy() for k, l in zip(keys, leaves)}})
     else:
         out.put({"same": same, "lo_hi": (lo, hi)})
@@ -92,6 +102,10 @@ def test_two_rank_gloo_matches_full_batch():
     assert abs(r0["stats"][0] - ll.double().sum().item()) <= 1e-6 * abs(ll.double().sum().item())
     assert abs(r0["stats"][1] - ld.double().sum().item()) <= 1e-6 * abs(ld.double().sum().item())
     assert r0["stats"][2] == B
+    tot = ll.double().sum().item()
+    for k, v in enumerate(r0["piped"]):                # steps 0,1,2 seen when their buffer is handed out again
+        assert abs(v[0] - tot * (k + 1)) <= 1e-6 * abs(tot * (k + 1)) and v[2] == B
+    assert abs(r0["fin"][0] - tot * 5) <= 1e-6 * abs(tot * 5) and r0["fin"][2] == B
     lo, hi = r0["lo_hi"]
     assert torch.allclose(torch.tensor(r0["ll"]), ll[lo:hi], rtol=1e-6, atol=1e-5)
     ref = O.grad_neg_mean_ll_wrt_params(p, z)

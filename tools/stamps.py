@@ -8,7 +8,7 @@ w = bench.synth_weights(1)
 plan = lsnf_amd.prepare([t.to(dev) for t in w], bench.NZ, bench.WIDTH, bench.DEPTH)
 z = torch.randn(bench.B_PER_GPU, bench.NZ, generator=torch.Generator().manual_seed(1234)).to(dev)
 out = (torch.empty_like(z), torch.empty(z.shape[0], device=dev), torch.empty(z.shape[0], device=dev))
-for _ in range(5):
+for _ in range(int(os.environ.get("STAMP_WARM", "5"))):
     lsnf_amd.forward(plan, z, out=out)
 torch.cuda.synchronize()
 lib = lsnf_amd.load_library()
@@ -40,3 +40,11 @@ rt = (s[:, :, 51] - s[:, :, 50]).astype(np.float64)       # 100 MHz ticks
 ok = rt > 0
 print(f"in-kernel clock = d(s_memtime)/d(s_memrealtime)*100MHz: median {np.median(cyc[ok] / rt[ok]) * 0.1:.3f} GHz; "
       f"wave lifetime median {np.median(rt[ok]) / 100:.1f} us, {np.median(cyc[ok]):.0f} cycles")
+st, en = s[:, :, 50].astype(np.float64) / 100.0, s[:, :, 51].astype(np.float64) / 100.0     # us (100 MHz realtime)
+t_first = st.min()
+print(f"kernel span by realtime stamps: first start 0, last end {en.max() - t_first:.1f} us")
+for q in (0, 5, 25, 50, 75, 95, 100):
+    print(f"  start p{q}: {np.percentile(st - t_first, q):7.1f} us    end p{q}: {np.percentile(en - t_first, q):7.1f} us")
+wg_start = st.min(axis=1) - t_first
+order = np.argsort(wg_start)
+print("workgroups starting later than 5 us:", int((wg_start > 5).sum()), " later than 50 us:", int((wg_start > 50).sum()))
