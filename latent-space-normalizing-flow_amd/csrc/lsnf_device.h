@@ -137,6 +137,19 @@ __device__ __forceinline__ f32x16 lsnf_relu16(f32x16 a) {
     return a;
 }
 
+// sig = sigmoid(p) and l2 = log2(1 + exp(-p)) = -log2(sigmoid(p)) on the hardware transcendentals
+// (v_exp_f32 / v_rcp_f32 / v_log_f32, <= 1 ulp each): 7 VALU instructions.  p is clamped to [-80, 80] (v_med3) so
+// that exp never overflows; |pre-sigmoid| beyond 80 does not occur (sigmoid saturates in fp32 at ~17), and the
+// clamp changes log(sigmoid) only where it is already < -80.  Absolute error of l2 <= ~1.5e-7 (rounding of 1+e),
+// i.e. ~1e-8 relative on a log-prob of magnitude 80 after summing a sample's 320 terms.
+__device__ __forceinline__ void lsnf_sigmoid_log2(float p, float& sig, float& l2) {
+    const float pc = __builtin_amdgcn_fmed3f(p, -80.0f, 80.0f);
+    const float e = __builtin_amdgcn_exp2f(pc * -1.4426950408889634f);    // exp(-p)
+    const float d = 1.0f + e;
+    sig = __builtin_amdgcn_rcpf(d);
+    l2 = __builtin_amdgcn_logf(d);                                         // v_log_f32 is log2
+}
+
 // sigma = sigmoid(p), lsig = log(sigmoid(p)), both stable for any finite p.
 //   reference: scale = sigmoid(h[:,1::2] + 2) (model.py:413; the +2 is folded into the bias),
 //              log(scale) (model.py:418)
@@ -144,24 +157,18 @@ __device__ __forceinline__ void lsnf_sigmoid_logsig(float p, float& sig, float& 
 #ifdef LSNF_ABLATE_EPILOGUE   // timing diagnostic only (wrong numbers): prices the transcendental epilogue
     sig = p * 0.25f + 0.5f; lsig = p; return;
 #endif
-    const float a = fabsf(p);
 #ifdef LSNF_OCML_MATH               // reference build of the epilogue on OCML expf/log1pf (slow, ~110 VALU/element)
+    const float a = fabsf(p);
     const float e = expf(-a);
     const float r = 1.0f / (1.0f + e);
     const float l = log1pf(e);
-#else
-    // Hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32: <= 1 ulp each), ~20 VALU/element.
-    //   e = exp(-a) in (0,1];  d = 1+e in [1,2];  dm1 = d-1 is exact;  log1p(e) = log(d) * e/dm1
-    // (the classic correction for the rounding of 1+e), and = e when 1+e rounds to 1.
-    const float e = __builtin_amdgcn_exp2f(a * -1.4426950408889634f);
-    const float d = 1.0f + e;
-    const float r = __builtin_amdgcn_rcpf(d);
-    const float dm1 = d - 1.0f;
-    const float lg = __builtin_amdgcn_logf(d) * 0.6931471805599453f;
-    const float l = (dm1 == 0.0f) ? e : lg * (e * __builtin_amdgcn_rcpf(dm1));
-#endif
     sig = (p >= 0.0f) ? r : e * r;
     lsig = fminf(p, 0.0f) - l;
+#else
+    float l2;
+    lsnf_sigmoid_log2(p, sig, l2);
+    lsig = -0.6931471805599453f * l2;
+#endif
 }
 
 // sum of a value held by lanes l and l+32 (the two feature half-groups of one sample)

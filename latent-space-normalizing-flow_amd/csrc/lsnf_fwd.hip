@@ -144,13 +144,13 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_fwd_kernel(const FwdA
             x[t] = v[t];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float sig, lsig;
-                lsnf_sigmoid_logsig(tp[HT + t][r], sig, lsig);
+                float sig, l2;
+                lsnf_sigmoid_log2(tp[HT + t][r], sig, l2);
                 x[HT + t][r] = (v[HT + t][r] + tp[t][r]) * sig;
-                lsum += lsig;
+                lsum += l2;                                   // -log2(scale); one multiply by -ln2 per sample below
             }
         }
-        ell = ell + lsnf_pair_sum(lsum);
+        ell = ell + -0.6931471805599453f * lsnf_pair_sum(lsum);
         LSNF_STAMP(2 + 6 * blk + 4);
 
         if (a.z_saved != nullptr && more && live)

@@ -110,10 +110,10 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_fwd_kernel(cons
             float lsum = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float sig, lsig;
-                lsnf_sigmoid_logsig(p[r], sig, lsig);
+                float sig, l2;
+                lsnf_sigmoid_log2(p[r], sig, l2);
                 y[r] = (v2[r] + t[r]) * sig;
-                lsum += lsig;
+                lsum += l2;
             }
             small_store_tile(Xn + (size_t)(HT + j) * LSNF_TILE_FLOATS, y, lane);
             aux[64 * j + lane] = lsum;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_fwd_kernel(cons
             float ls = 0.0f;
 #pragma unroll
             for (int j = 0; j < HT; ++j) ls += aux[64 * j + lane];
-            ell = ell + lsnf_pair_sum(ls);
+            ell = ell + -0.6931471805599453f * lsnf_pair_sum(ls);
         }
         if (a.z_saved != nullptr && more && wave < NZT && live)
             lsnf_store_tile<HT>(wave, small_load_tile(Xn + (size_t)wave * LSNF_TILE_FLOATS, lane),
