@@ -197,7 +197,12 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_fwd_kernel(const FwdA
             unsigned long long* ticket = reinterpret_cast<unsigned long long*>(&a.stats[2]);
             const unsigned long long t = atomicAdd(ticket, inc);
             if (t == (unsigned long long)gridDim.x - 1) {   // last workgroup: publish and re-arm for the next launch
-                const double fl = atomicAdd(&a.stats[0], 0.0), fd = atomicAdd(&a.stats[1], 0.0);
+// every other workgroup's adds were performed before its ticket.  The totals are read with atomic
+                // read-modify-writes (performed at the memory side like the adds: a plain or sc1 load could be served
+                // by this XCD's L2, which is not coherent with the other XCDs); the two reads are independent, so
+                // they cost one round trip; the re-arming atomics are fire-and-forget.
+                const double fl = atomicAdd(&a.stats[0], 0.0);
+                const double fd = atomicAdd(&a.stats[1], 0.0);
                 a.stats[4] = fl; a.stats[5] = fd; a.stats[6] = (double)a.B;
                 atomicAdd(&a.stats[0], -fl); atomicAdd(&a.stats[1], -fd);
                 atomicExch(ticket, 0ull);
