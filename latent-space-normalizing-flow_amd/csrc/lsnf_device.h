@@ -8,11 +8,6 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef LSNF_STAGGER_MODE_DEFAULT
-#define LSNF_STAGGER_MODE_DEFAULT 0
-#define LSNF_STAGGER_COUNT_DEFAULT 0
-#endif
-#include <stdio.h>
 #define LSNF_WG_THREADS 256          // 4 waves, one per SIMD; 2 workgroups co-resident per CU
 #define LSNF_WG_WAVES 4
 #define LSNF_WG_SAMPLES (LSNF_WG_WAVES * 32)
@@ -22,37 +17,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // feature offset inside a 32-tile of accumulator register r on lane-half h
 __device__ __forceinline__ constexpr int lsnf_feat(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-// ---- start-up stagger of the two workgroups that share a CU ------------------------------------------
-// The two waves on a SIMD (one from each co-resident workgroup) run the same program; in lockstep they hit
-// their MFMA-free phases (prologue loads, panel starts, sigmoid/log epilogue, stores) together and the
-// matrix pipe idles.  Delaying one of them once at start-up makes those phases complementary
-// (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  Speed only, never correctness.
-//   mode 0: off; 1: waves in an odd hardware wave slot (HW_ID.wave_id & 1); 2: odd blockIdx; 3: upper half of the grid
-__device__ __forceinline__ void lsnf_stagger(int mode, int count) {
-    if (mode == 0) return;
-    bool late;
-    if (mode == 1) late = (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1) != 0;   // HW_REG_HW_ID[3:0] = wave slot
-    else if (mode == 2) late = (blockIdx.x & 1) != 0;
-    else late = blockIdx.x >= (gridDim.x >> 1);
-    if (__builtin_amdgcn_readfirstlane(late ? 1 : 0))
-        for (int i = 0; i < count; ++i) __builtin_amdgcn_s_sleep(16);             // ~1024 cycles each
-}
-#ifndef __HIP_DEVICE_COMPILE__
-#include <stdlib.h>
-// LSNF_STAGGER="mode,count" overrides the built-in default (tuning knob).
-static inline void lsnf_stagger_config(int* mode, int* count) {
-    static int m = -1, c = 0;
-    if (m < 0) {
-        m = LSNF_STAGGER_MODE_DEFAULT; c = LSNF_STAGGER_COUNT_DEFAULT;
-        const char* e = getenv("LSNF_STAGGER");
-        if (e) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2) { m = a; c = b; } }
-    }
-    *mode = m; *count = c;
-}
-#else
-static inline void lsnf_stagger_config(int*, int*) {}
-#endif
 
 // ---- LDS-DMA of one weight panel (KT KiB*4) by the 4 waves of the workgroup -------------------
 // Each wave-instruction moves 1 KiB (64 lanes x 16 B), destination = wave-uniform base + lane*16.

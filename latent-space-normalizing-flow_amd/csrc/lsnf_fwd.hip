@@ -41,7 +41,6 @@ struct FwdArgs {
     float* ll_out;
     float* z_saved;
     int B, nz, half, n_blocks, vec4;
-    int stagger_mode, stagger_count;   // see lsnf_stagger() in lsnf_device.h
     double* stats;                     // NULL or 8 doubles: see lsnf_forward (in-kernel sum of ll / logdet over the batch)
     unsigned long long* stamps;        // LSNF_STAMPS diagnostic build only: [grid][4 waves][64] shader-clock stamps
 };
@@ -75,7 +74,6 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_fwd_kernel(const FwdA
 
     LSNF_STAMP(0);
     LSNF_STAMP_RT(50);
-    lsnf_stagger(a.stagger_mode, a.stagger_count);
     // prologue: first panel pair in flight, constants to LDS, latent rows to registers
     LsnfPipe pipe;
     pipe.buf0 = buf0; pipe.slot = C::SLOT; pipe.wave = wave; pipe.lane = lane;
@@ -99,11 +97,7 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_fwd_kernel(const FwdA
 #endif
 
     LSNF_STAMP(1);
-    const int slot = __builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1));   // HW wave slot parity
-    if (a.stagger_mode == 4) { if (slot) __builtin_amdgcn_s_setprio(1); }
     for (int blk = 0; blk < a.n_blocks; ++blk) {
-        // experimental fairness knob (speed only): the two co-resident workgroups alternate issue priority per block
-        if (a.stagger_mode == 5) { if ((blk ^ slot) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         const float* cb = cst + blk * C::CONST_FLOATS;
         const float* gblk = a.panels + (size_t)blk * C::BLOCK_FLOATS;
         const bool more = blk + 1 < a.n_blocks;
@@ -246,7 +240,6 @@ hipError_t lsnf_launch_forward(const LsnfGeo& g, const float* plan, int first_bl
     a.panels = plan + g.off_fwd_panels + (size_t)first_block * g.fwd_block_floats;
     a.z_in = z_in; a.objective = objective; a.z_out = z_out; a.logdet_out = logdet_out; a.ll_out = ll_out;
     a.z_saved = z_saved; a.B = B; a.nz = g.nz; a.half = g.half; a.n_blocks = n_blocks; a.vec4 = vec4;
-    lsnf_stagger_config(&a.stagger_mode, &a.stagger_count);
     a.stamps = nullptr;
 #ifdef LSNF_STAMPS
     {   // diagnostic build: a leaked device buffer, address published through LSNF_STAMPS_PTR (see tools/stamps.py)

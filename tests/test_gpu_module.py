@@ -101,7 +101,7 @@ def test_flow_mle_call_site_param_grads(lsnf, gpu_device, name):
 
 
 @pytest.mark.parametrize("name", golden_names())
-def test_reverse_call_sites(lsnf, gpu_device, name):
+def test_reverse_call_sites(lsnf, kernels, gpu_device, name):
     """train.py:433-434 (return z) and model.py:495-498 (return_obj=True -> (z, -objective))."""
     p, g = load_golden(name)
     net, nz = make_net(lsnf, p, g, gpu_device)

@@ -24,7 +24,7 @@ def _plan(lsnf, p, g, dev):
 
 
 @pytest.mark.parametrize("name", golden_names())
-def test_reverse_matches_reference_golden(lsnf, gpu_device, name):
+def test_reverse_matches_reference_golden(lsnf, kernels, gpu_device, name):
     p, g = load_golden(name)
     plan = _plan(lsnf, p, g, gpu_device)
     x, obj = lsnf.reverse(plan, torch.from_numpy(g["rev_in"]).to(gpu_device))
@@ -35,7 +35,7 @@ def test_reverse_matches_reference_golden(lsnf, gpu_device, name):
 
 
 @pytest.mark.parametrize("name", golden_names())
-def test_roundtrip_forward_reverse(lsnf, gpu_device, name):
+def test_roundtrip_forward_reverse(lsnf, kernels, gpu_device, name):
     """forward o reverse = identity and the two log-dets cancel (the flow's own self-check)."""
     p, g = load_golden(name)
     plan = _plan(lsnf, p, g, gpu_device)
