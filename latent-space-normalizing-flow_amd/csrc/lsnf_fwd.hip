@@ -111,6 +111,13 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_fwd_kernel(const FwdA
         lsnf_gemm_stage<C::P1, C::KT1, lsnf_first_ktc(C::P2, C::KT2)>(
             pipe, gblk, gblk + C::OFF_S2, v, x, [&](int t) { return lsnf_bias_init(cb + 32 * t, h); }, keep);
         LSNF_STAMP(2 + 6 * blk + 0);
+        // last block: its v1 half is already final (the coupling passes it through, model.py:422) -- store it now, under
+        // the MFMAs of S2..S4, instead of in the store burst at the end of the kernel
+        if (!more && live) {
+            float* zo = a.z_out + sample * (long)a.nz;
+#pragma unroll
+            for (int t = 0; t < HT; ++t) lsnf_store_tile<HT>(t, v[t], zo, a.half, h, a.vec4 != 0);
+        }
         // logdet += sum(3*logs) (model.py:273-276); logdet += log|det W| (model.py:182,189)
         ell = ell + cb[32 * C::NP + 0];
         ell = ell + cb[32 * C::NP + 1];
@@ -162,7 +169,11 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_fwd_kernel(const FwdA
     if (ss != 123.456f) return;   // keeps the computation alive, stores (practically) never happen
 #endif
     if (live) {
-        lsnf_store_rows<HT>(x, a.z_out, sample, a.nz, a.half, h, a.vec4 != 0);
+        {   // second half only: the first half went out during the last block
+            float* zo = a.z_out + sample * (long)a.nz;
+#pragma unroll
+            for (int t = HT; t < NZT; ++t) lsnf_store_tile<HT>(t, x[t], zo, a.half, h, a.vec4 != 0);
+        }
         if (h == 0) {
             a.logdet_out[sample] = ell;
             if (a.ll_out) a.ll_out[sample] = (-0.5f * ss + 1.8378770664093453f) + ell;
