@@ -20,17 +20,21 @@ __device__ __forceinline__ constexpr int lsnf_feat(int r, int h) { return (r & 3
 
 // ---- LDS-DMA of one weight panel (KT KiB*4) by the 4 waves of the workgroup -------------------
 // Each wave-instruction moves 1 KiB (64 lanes x 16 B), destination = wave-uniform base + lane*16.
-template <int KT>
+template <int KT, int NW = LSNF_WG_WAVES>
 __device__ __forceinline__ void lsnf_issue_panel(const float* __restrict__ gsrc, float* lbuf, int wave, int lane) {
 #ifdef LSNF_ABLATE_DMA   // timing diagnostic only (wrong numbers): prices the L2 -> LDS weight stream and its power
     return;
 #endif
+    constexpr int PIECES = 4 * KT;                 // 1 KiB pieces of this panel (pair)
+    constexpr int PER_WAVE = (PIECES + NW - 1) / NW;
 #pragma unroll
-    for (int s = 0; s < KT; ++s) {
-        const int seg = s * LSNF_WG_WAVES + wave;  // 1 KiB segment index
-        const float* g = gsrc + seg * 256 + lane * 4;
-        float* l = lbuf + seg * 256;
-        __builtin_amdgcn_global_load_lds((const LSNF_AS1 void*)g, (LSNF_AS3 void*)l, 16, 0, 0);
+    for (int s = 0; s < PER_WAVE; ++s) {
+        const int seg = s * NW + wave;             // 1 KiB segment index
+        if (PIECES % NW == 0 || seg < PIECES) {    // wave-uniform
+            const float* g = gsrc + seg * 256 + lane * 4;
+            float* l = lbuf + seg * 256;
+            __builtin_amdgcn_global_load_lds((const LSNF_AS1 void*)g, (LSNF_AS3 void*)l, 16, 0, 0);
+        }
     }
 }
 
@@ -201,7 +205,8 @@ __device__ __forceinline__ void lsnf_store_rows(const f32x16* x, float* __restri
 // ago is now complete in buf[cur] and every wave is done with buf[cur^1]; (2) start the LDS-DMA of
 // the NEXT panel (KT_NEXT k-tiles at `next`, or nothing if next == nullptr) into buf[cur^1];
 // (3) return buf[cur] for the MFMAs and flip.  The very first panel is issued with prime<KT>().
-struct LsnfPipe {
+template <int NW>
+struct LsnfPipeT {
     float* buf0;
     int slot;     // floats per buffer
     int cur;      // wave-uniform
@@ -209,18 +214,19 @@ struct LsnfPipe {
 
     template <int KT>
     __device__ __forceinline__ void prime(const float* src) {
-        lsnf_issue_panel<KT>(src, buf0, wave, lane);
+        lsnf_issue_panel<KT, NW>(src, buf0, wave, lane);
         cur = 0;
     }
     template <int KT_NEXT>
     __device__ __forceinline__ const float* acquire(const float* next) {
         lsnf_panel_barrier();
-        if (next != nullptr) lsnf_issue_panel<KT_NEXT>(next, buf0 + (cur ^ 1) * slot, wave, lane);
+        if (next != nullptr) lsnf_issue_panel<KT_NEXT, NW>(next, buf0 + (cur ^ 1) * slot, wave, lane);
         const float* ready = buf0 + cur * slot;
         cur ^= 1;
         return ready;
     }
 };
+using LsnfPipe = LsnfPipeT<LSNF_WG_WAVES>;
 
 template <int N, class F, int I = 0>
 __device__ __forceinline__ void lsnf_static_for(F&& f) {
@@ -270,8 +276,8 @@ __device__ __forceinline__ void lsnf_panel_mma2(f32x16& acc0, f32x16& acc1, cons
 // ---- one GEMM stage: out[t] = post(init(t) + W_t^T in), t < NT, streamed as panel PAIRS -----------------
 // gsrc: this stage's packed panels (n-tile major, KT k-tiles each).  gnext/NEXT_KTC: first panel (pair) of
 // whatever follows this stage (NEXT_KTC = its k-tiles x its tile count; gnext == nullptr: nothing follows).
-template <int NT, int KT, int NEXT_KTC, class Init, class Post>
-__device__ __forceinline__ void lsnf_gemm_stage(LsnfPipe& pipe, const float* gsrc, const float* gnext, f32x16* out,
+template <int NT, int KT, int NEXT_KTC, class Pipe, class Init, class Post>
+__device__ __forceinline__ void lsnf_gemm_stage(Pipe& pipe, const float* gsrc, const float* gnext, f32x16* out,
                                                 const f32x16* in, Init&& init, Post&& post) {
     constexpr int NSP = (NT + 1) / 2;
     lsnf_static_for<NSP>([&](auto qc) {

@@ -50,19 +50,23 @@ struct FwdArgs {
     do { __builtin_amdgcn_sched_barrier(0);                                                             \
          unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
          __builtin_amdgcn_sched_barrier(0);                                                             \
-         if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wave) * 64 + (i)] = t_; } while (0)
+         if (a.stamps && lane == 0) a.stamps[(((size_t)blockIdx.x * FWD_WAVES + wave) & 2047) * 64 + (i)] = t_; } while (0)
 #define LSNF_STAMP_RT(i)                                                                                \
     do { __builtin_amdgcn_sched_barrier(0);                                                             \
          unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
          __builtin_amdgcn_sched_barrier(0);                                                             \
-         if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wave) * 64 + (i)] = t_; } while (0)
+         if (a.stamps && lane == 0) a.stamps[(((size_t)blockIdx.x * FWD_WAVES + wave) & 2047) * 64 + (i)] = t_; } while (0)
 #else
 #define LSNF_STAMP(i) do {} while (0)
 #define LSNF_STAMP_RT(i) do {} while (0)
 #endif
 
-template <class C>
-__global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_fwd_kernel(const FwdArgs a) {
+// FWD_WAVES waves per workgroup, 2 waves per SIMD either way: 4 -> two workgroups of 128 rows per CU, 8 -> one workgroup of
+// 256 rows per CU.  The 8-wave form halves the LDS-DMA pieces each wave has to issue per row (every panel is shared by
+// twice as many rows; measured -5 us at B = 65536) but needs B > 32768 to put a workgroup on every CU.
+template <class C, int FWD_WAVES>
+__global__ __launch_bounds__(64 * FWD_WAVES, 2) void lsnf_fwd_kernel(const FwdArgs a) {
+    constexpr int FWD_THREADS = 64 * FWD_WAVES;
     constexpr int HT = C::HT, WT = C::WT, NZT = C::NZT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* cst = smem;                                         // n_blocks * CONST_FLOATS
@@ -75,12 +79,12 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_fwd_kernel(const FwdA
     LSNF_STAMP(0);
     LSNF_STAMP_RT(50);
     // prologue: first panel pair in flight, constants to LDS, latent rows to registers
-    LsnfPipe pipe;
+    LsnfPipeT<FWD_WAVES> pipe;
     pipe.buf0 = buf0; pipe.slot = C::SLOT; pipe.wave = wave; pipe.lane = lane;
-    pipe.prime<lsnf_first_ktc(C::P1, C::KT1)>(a.panels);
-    for (int i = tid; i < a.n_blocks * C::CONST_FLOATS; i += LSNF_WG_THREADS) cst[i] = a.consts[i];
+    pipe.template prime<lsnf_first_ktc(C::P1, C::KT1)>(a.panels);
+    for (int i = tid; i < a.n_blocks * C::CONST_FLOATS; i += FWD_THREADS) cst[i] = a.consts[i];
 
-    const long sample = ((long)blockIdx.x * LSNF_WG_WAVES + wave) * 32 + m;
+    const long sample = ((long)blockIdx.x * FWD_WAVES + wave) * 32 + m;
     const bool live = sample < a.B;
     const long row = live ? sample : (long)a.B - 1;
 
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_fwd_kernel(const FwdA
         __syncthreads();
         if (tid == 0) {
             double tl = 0.0, td = 0.0;
-            for (int w = 0; w < LSNF_WG_WAVES; ++w) { tl += red[2 * w]; td += red[2 * w + 1]; }
+            for (int w = 0; w < FWD_WAVES; ++w) { tl += red[2 * w]; td += red[2 * w + 1]; }
             // Returning atomics: their values come back only after the adds have been performed at the memory
             // side, and the ticket increment is made to depend on them -- ordering without an L2 write-back fence
             // (a release fence here would flush this workgroup's freshly written z_out lines: +2..6 us per WG).
@@ -220,21 +224,26 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_fwd_kernel(const FwdA
     LSNF_STAMP_RT(51);
 }
 
-template <class C>
-hipError_t launch_fwd(const FwdArgs& a, hipStream_t stream) {
+template <class C, int FWD_WAVES>
+hipError_t launch_fwd_w(const FwdArgs& a, hipStream_t stream) {
     const size_t lds = ((size_t)a.n_blocks * C::CONST_FLOATS + 2 * (size_t)C::SLOT) * sizeof(float);
+    auto kern = lsnf_fwd_kernel<C, FWD_WAVES>;
     static bool attr_set = false;  // benign race: idempotent
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)lsnf_fwd_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const unsigned grid = (unsigned)((a.B + LSNF_WG_SAMPLES - 1) / LSNF_WG_SAMPLES);
-    hipLaunchKernelGGL(lsnf_fwd_kernel<C>, dim3(grid), dim3(LSNF_WG_THREADS), lds, stream, a);
+    const unsigned grid = (unsigned)((a.B + 32 * FWD_WAVES - 1) / (32 * FWD_WAVES));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * FWD_WAVES), lds, stream, a);
     return hipGetLastError();
 }
 
+template <class C>
+hipError_t launch_fwd(const FwdArgs& a, hipStream_t stream) {
+    // more than 256 four-wave workgroups would double up on CUs anyway: switch to one eight-wave workgroup per CU
+    return a.B > 256 * 128 ? launch_fwd_w<C, 8>(a, stream) : launch_fwd_w<C, 4>(a, stream);
+}
 }  // namespace
 
 #ifdef LSNF_STAMPS

@@ -14,11 +14,11 @@ torch.cuda.synchronize()
 lib = lsnf_amd.load_library()
 lib.lsnf_debug_stamps.restype = ctypes.c_void_p
 ptr = lib.lsnf_debug_stamps()
-n = 512 * 4 * 64
+n = 2048 * 64
 buf = (ctypes.c_ulonglong * n)()
 hip = ctypes.CDLL("libamdhip64.so")
 hip.hipMemcpy(buf, ctypes.c_void_p(ptr), ctypes.c_size_t(n * 8), 2)
-s = np.frombuffer(buf, dtype=np.uint64).reshape(512, 4, 64).astype(np.int64)
+s = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 1, 64).astype(np.int64)
 t0 = s[:, :, 0].min()
 rel = s - t0
 names = ["prologue(load z, consts, first acquire)"] + [f"blk{b} {st}" for b in range(5) for st in ("S1", "S2", "S3", "S4", "epilogue")] 
