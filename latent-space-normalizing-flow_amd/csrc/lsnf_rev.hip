@@ -30,25 +30,26 @@ struct RevArgs {
     int B, nz, half, depth, vec4;
 };
 
-template <class C>
-__global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_rev_kernel(const RevArgs a) {
+// NW waves per workgroup (4: two workgroups per CU, 8: one; see lsnf_fwd.hip)
+template <class C, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void lsnf_rev_kernel(const RevArgs a) {
     constexpr int HT = C::HT, WT = C::WT, NZT = C::NZT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* cst = smem;                                   // depth * (FWD_CONST + INV_CONST)
     const int tid = threadIdx.x;
-    LsnfPipe pipe;
+    LsnfPipeT<NW> pipe;
     pipe.buf0 = smem + a.depth * C::CONST_PER_BLOCK;
     pipe.slot = C::SLOT;
     pipe.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     pipe.lane = tid & 63;
     const int lane = pipe.lane, m = lane & 31, h = lane >> 5;
 
-    pipe.prime<HT>(a.fwd_panels + (size_t)(a.depth - 1) * C::FWD_BLOCK + C::OFF_S2);
-    for (int i = tid; i < a.depth * C::CONST_PER_BLOCK; i += LSNF_WG_THREADS) {
+    pipe.template prime<HT>(a.fwd_panels + (size_t)(a.depth - 1) * C::FWD_BLOCK + C::OFF_S2);
+    for (int i = tid; i < a.depth * C::CONST_PER_BLOCK; i += 64 * NW) {
         const int blk = i / C::CONST_PER_BLOCK, r = i % C::CONST_PER_BLOCK;
         cst[i] = r < C::FWD_CONST ? a.fwd_consts[blk * C::FWD_CONST + r] : a.inv_consts[blk * C::INV_CONST + (r - C::FWD_CONST)];
     }
-    const long sample = ((long)blockIdx.x * LSNF_WG_WAVES + pipe.wave) * 32 + m;
+    const long sample = ((long)blockIdx.x * NW + pipe.wave) * 32 + m;
     const bool live = sample < a.B;
     const long row = live ? sample : (long)a.B - 1;
     f32x16 x[NZT];
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_rev_kernel(const RevA
         f32x16 h1[WT];
         lsnf_static_for<WT>([&](auto nt) {
             const float* nxt = (nt + 1 < WT) ? gf + C::OFF_S2 + (nt + 1) * HT * LSNF_FRAG_FLOATS : gf + C::OFF_S3;
-            const float* lb = (nt + 1 < WT) ? pipe.acquire<HT>(nxt) : pipe.acquire<WT>(nxt);
+            const float* lb = (nt + 1 < WT) ? pipe.template acquire<HT>(nxt) : pipe.template acquire<WT>(nxt);
             h1[nt] = lsnf_bias_init(cb + 32 * (C::P1 + nt), h);
             lsnf_panel_mma<HT>(h1[nt], x, lb, lane);
             h1[nt] = lsnf_relu16(h1[nt]);
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_rev_kernel(const RevA
         f32x16 h2[WT];
         lsnf_static_for<WT>([&](auto nt) {
             const float* nxt = (nt + 1 < WT) ? gf + C::OFF_S3 + (nt + 1) * WT * LSNF_FRAG_FLOATS : gf + C::OFF_S4;
-            const float* lb = pipe.acquire<WT>(nxt);
+            const float* lb = pipe.template acquire<WT>(nxt);
             h2[nt] = lsnf_bias_init(cb + 32 * (C::P1 + C::P2 + nt), h);
             lsnf_panel_mma<WT>(h2[nt], h1, lb, lane);
             h2[nt] = lsnf_relu16(h2[nt]);
@@ -82,8 +83,8 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_rev_kernel(const RevA
         f32x16 tp[2 * HT];
         lsnf_static_for<2 * HT>([&](auto nt) {
             const float* lb;
-            if constexpr (nt + 1 < 2 * HT) lb = pipe.acquire<WT>(gf + C::OFF_S4 + (nt + 1) * WT * LSNF_FRAG_FLOATS);
-            else lb = pipe.acquire<NZT>(gi);
+            if constexpr (nt + 1 < 2 * HT) lb = pipe.template acquire<WT>(gf + C::OFF_S4 + (nt + 1) * WT * LSNF_FRAG_FLOATS);
+            else lb = pipe.template acquire<NZT>(gi);
             tp[nt] = lsnf_bias_init(cb + 32 * (C::P1 + C::P2 + C::P3 + nt), h);
             lsnf_panel_mma<WT>(tp[nt], h2, lb, lane);
         });
@@ -103,8 +104,8 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_rev_kernel(const RevA
         f32x16 y[NZT];
         lsnf_static_for<NZT>([&](auto nt) {
             const float* lb;
-            if constexpr (nt + 1 < NZT) lb = pipe.acquire<NZT>(gi + (nt + 1) * NZT * LSNF_FRAG_FLOATS);
-            else lb = pipe.acquire<HT>(gnext);
+            if constexpr (nt + 1 < NZT) lb = pipe.template acquire<NZT>(gi + (nt + 1) * NZT * LSNF_FRAG_FLOATS);
+            else lb = pipe.template acquire<HT>(gnext);
             y[nt] = lsnf_bias_init(ci + 32 * nt, h);
             lsnf_panel_mma<NZT>(y[nt], x, lb, lane);
         });
@@ -119,18 +120,23 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 2) void lsnf_rev_kernel(const RevA
     }
 }
 
-template <class C>
-hipError_t launch_rev(const RevArgs& a, hipStream_t stream) {
+template <class C, int NW>
+hipError_t launch_rev_w(const RevArgs& a, hipStream_t stream) {
     const size_t lds = ((size_t)a.depth * C::CONST_PER_BLOCK + 2 * (size_t)C::SLOT) * sizeof(float);
+    auto kern = lsnf_rev_kernel<C, NW>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)lsnf_rev_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const unsigned grid = (unsigned)((a.B + LSNF_WG_SAMPLES - 1) / LSNF_WG_SAMPLES);
-    hipLaunchKernelGGL(lsnf_rev_kernel<C>, dim3(grid), dim3(LSNF_WG_THREADS), lds, stream, a);
+    const unsigned grid = (unsigned)((a.B + 32 * NW - 1) / (32 * NW));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, a);
     return hipGetLastError();
+}
+template <class C>
+hipError_t launch_rev(const RevArgs& a, hipStream_t stream) {
+    return a.B > 256 * 128 ? launch_rev_w<C, 8>(a, stream) : launch_rev_w<C, 4>(a, stream);
 }
 }  // namespace
 
