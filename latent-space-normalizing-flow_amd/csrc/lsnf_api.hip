@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <initializer_list>
 #include <stdlib.h>
 #ifndef LSNF_SMALL_MAX_DEFAULT
 #define LSNF_SMALL_MAX_DEFAULT 16384
@@ -52,6 +53,15 @@ int hip_fail(hipError_t e, const char* what) {
     return fail(LSNF_E_HIP, "%s: %s", what, hipGetErrorString(e));
 }
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
+// vector width of the latent-row accesses: every (B, nz) tensor of the call must allow it (NULL pointers do)
+int row_vector_width(const LsnfGeo& g, std::initializer_list<const void*> rows) {
+    bool a16 = true, a8 = true;
+    for (const void* p : rows) { a16 = a16 && aligned16(p); a8 = a8 && aligned8(p); }
+    if (g.half % 4 == 0 && a16) return 4;
+    if (g.half % 2 == 0 && a8) return 2;
+    return 1;
+}
 bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
 
 // rows at or below which the small-batch kernels are used (LSNF_SMALL_MAX overrides; 0 disables them)
@@ -137,7 +147,7 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
     if (!aligned4(z_in) || !aligned4(z_out) || !aligned4(logdet_out) || !aligned4(objective) || !aligned4(ll_out) || !aligned4(z_saved))
         return fail(LSNF_E_ARG, "lsnf_forward: tensors must be 4-byte aligned");
     if (B == 0) return LSNF_OK;
-    const int vec4 = (g.half % 4 == 0) && aligned16(z_in) && aligned16(z_out) && (z_saved == nullptr || aligned16(z_saved));
+    const int vec4 = row_vector_width(g, {z_in, z_out, z_saved});
     if (stats && (reinterpret_cast<uintptr_t>(stats) & 7u)) return fail(LSNF_E_ARG, "lsnf_forward: stats must be 8-byte aligned");
     // batch-size dispatch: latency kernel (32 rows per workgroup, stages split over the 4 waves) below the
     // crossover, throughput kernel (128 rows per workgroup, weights shared through LDS) above it
@@ -161,7 +171,7 @@ int lsnf_reverse(const float* plan, int nz, int width, int depth, int coupling, 
     if (!aligned4(z_in) || !aligned4(z_out) || !aligned4(objective) || !aligned4(objective_out))
         return fail(LSNF_E_ARG, "lsnf_reverse: tensors must be 4-byte aligned");
     if (B == 0) return LSNF_OK;
-    const int vec4 = (g.half % 4 == 0) && aligned16(z_in) && aligned16(z_out);
+    const int vec4 = row_vector_width(g, {z_in, z_out});
     hipError_t e = (B <= small_batch_max())
         ? lsnf_launch_small_reverse(g, plan, B, z_in, objective, z_out, objective_out, vec4, (hipStream_t)stream)
         : lsnf_launch_reverse(g, plan, B, z_in, objective, z_out, objective_out, vec4, (hipStream_t)stream);
@@ -181,8 +191,7 @@ int lsnf_backward_z(const float* plan, int nz, int width, int depth, int couplin
     if (!aligned4(z_out) || !aligned4(z_saved) || !aligned4(g_z1) || !aligned4(g_logdet) || !aligned4(g_z_in))
         return fail(LSNF_E_ARG, "lsnf_backward_z: tensors must be 4-byte aligned");
     if (B == 0) return LSNF_OK;
-    const int vec4 = (g.half % 4 == 0) && aligned16(z_out) && aligned16(g_z_in) && (z_saved == nullptr || aligned16(z_saved)) &&
-                     (g_z1 == nullptr || aligned16(g_z1));
+    const int vec4 = row_vector_width(g, {z_out, g_z_in, z_saved, g_z1});
     hipError_t e = (B <= small_batch_max())
         ? lsnf_launch_small_backward_z(g, plan, B, z_out, z_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, vec4,
                                        (hipStream_t)stream, nullptr)
@@ -204,7 +213,7 @@ int lsnf_langevin_step(const float* plan, int nz, int width, int depth, int coup
     if (!aligned4(z_cur) || !aligned4(z_out) || !aligned4(z_saved) || !aligned4(grad_g) || !aligned4(noise) || !aligned4(z_new) ||
         !aligned4(gf_norm) || !aligned4(gg_norm))
         return fail(LSNF_E_ARG, "lsnf_langevin_step: tensors must be 4-byte aligned");
-    const int vec4 = (g.half % 4 == 0) && aligned16(z_out) && (z_saved == nullptr || aligned16(z_saved));
+    const int vec4 = row_vector_width(g, {z_out, z_saved, z_cur, grad_g, noise, z_new});
     LsnfLangevinArgs lv = {z_cur, grad_g, noise, z_new, gf_norm, gg_norm, step_size};
     hipError_t e = (B <= small_batch_max())
         ? lsnf_launch_small_backward_z(g, plan, B, z_out, z_saved, nullptr, nullptr, /*ll_mode=*/1, /*ll_scale=*/-1.0f,
@@ -237,8 +246,7 @@ int lsnf_backward_params(const float* plan, const float* const* params_host, flo
     }
     if (!aligned4(z_in) || !aligned4(z_out) || !aligned4(z_saved) || !aligned4(g_z1) || !aligned4(g_logdet) || !aligned4(g_z_in))
         return fail(LSNF_E_ARG, "lsnf_backward_params: tensors must be 4-byte aligned");
-    const int vec4 = (g.half % 4 == 0) && aligned16(z_out) && (g_z_in == nullptr || aligned16(g_z_in)) &&
-                     (z_saved == nullptr || aligned16(z_saved)) && (g_z1 == nullptr || aligned16(g_z1));
+    const int vec4 = row_vector_width(g, {z_out, g_z_in, z_saved, g_z1});
     hipError_t e = lsnf_launch_backward_params(g, plan, params_host, grads_host, B, z_in, z_out, z_saved, g_z1, g_logdet,
                                                ll_mode, ll_scale, g_z_in, workspace, vec4, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "lsnf_backward_params launch");

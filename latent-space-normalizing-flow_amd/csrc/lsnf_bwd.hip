@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lsnf_bwd_z_kernel(const BwdArgs a)
     const long sample = ((long)blockIdx.x * NW + pipe.wave) * 32 + m;
     const bool live = sample < a.B;
     const long row = live ? sample : (long)a.B - 1;
-    const bool vec4 = a.vec4 != 0;
+    const int vec4 = a.vec4;
 
     // upstream gradient on the stack output
     f32x16 gx[NZT];
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lsnf_bwd_z_kernel(const BwdArgs a)
         });
 #pragma unroll
         for (int t = 0; t < HT; ++t) gv[HT + t] = tp[t];
-        if constexpr (DUMP) { if (live) lsnf_store_rows<HT>(gv, dmp + dl.off_gv, sample, a.nz, a.half, h, false); }
+        if constexpr (DUMP) { if (live) lsnf_store_rows<HT>(gv, dmp + dl.off_gv, sample, a.nz, a.half, h, vec4); }
         // ---- B1: g_x = Wa gv ----
         lsnf_static_for<NZT>([&](auto nt) {
             const float* lb;
@@ -234,12 +234,12 @@ __global__ __launch_bounds__(64 * NW, 2) void lsnf_bwd_z_kernel(const BwdArgs a)
         float* zo = a.z_new + row * (long)a.nz;
 #pragma unroll
         for (int t = 0; t < NZT; ++t) {
-            const f32x16 zc = lsnf_load_tile<HT>(t, zr, a.half, h, false);
+            const f32x16 zc = lsnf_load_tile<HT>(t, zr, a.half, h, vec4);
             f32x16 g = gx[t];
 #pragma unroll
             for (int r = 0; r < 16; ++r) gf2 += g[r] * g[r];
             if (a.grad_g) {
-                const f32x16 gg = lsnf_load_tile<HT>(t, a.grad_g + row * (long)a.nz, a.half, h, false);
+                const f32x16 gg = lsnf_load_tile<HT>(t, a.grad_g + row * (long)a.nz, a.half, h, vec4);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { gg2 += gg[r] * gg[r]; g[r] = gg[r] + g[r]; }   // z_grad_g + z_grad_f (train.py:324)
             }
@@ -247,11 +247,11 @@ __global__ __launch_bounds__(64 * NW, 2) void lsnf_bwd_z_kernel(const BwdArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) zn[r] = zc[r] - coef * g[r];
             if (a.noise) {
-                const f32x16 nv = lsnf_load_tile<HT>(t, a.noise + row * (long)a.nz, a.half, h, false);
+                const f32x16 nv = lsnf_load_tile<HT>(t, a.noise + row * (long)a.nz, a.half, h, vec4);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) zn[r] = zn[r] + a.step * nv[r];                    // train.py:326
             }
-            if (live) lsnf_store_tile<HT>(t, zn, zo, a.half, h, false);
+            if (live) lsnf_store_tile<HT>(t, zn, zo, a.half, h, vec4);
         }
         gf2 = lsnf_pair_sum(gf2);
         gg2 = lsnf_pair_sum(gg2);

@@ -144,18 +144,26 @@ __device__ __forceinline__ float lsnf_pair_sum(float v) { return v + __shfl_xor(
 
 // ---- latent rows <-> split-pad register tiles -------------------------------------------------
 // row: sample index (already clamped to [0,B)), tile t of the split-pad row: x[r] <- feature nat(32*t + o(r,h)).
+// vw = vector width of the global accesses: 4 (half % 4 == 0, 16-byte aligned rows), 2 (half even, 8-byte aligned:
+// e.g. nz = 100) or 1.  A 4-feature group never straddles the valid / padded boundary at its own granularity.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int HT>
-__device__ __forceinline__ f32x16 lsnf_load_tile(int t, const float* __restrict__ zr, int half, int h, bool vec4) {
+__device__ __forceinline__ f32x16 lsnf_load_tile(int t, const float* __restrict__ zr, int half, int h, int vw) {
     f32x16 x;
     const int hh = t / HT, tt = t % HT;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int f0 = 32 * tt + 8 * g + 4 * h;
         const int col0 = hh * half + f0;
-        if (vec4) {
+        if (vw == 4) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (f0 < half) v = *reinterpret_cast<const f32x4*>(zr + col0);
             x[4 * g + 0] = v[0]; x[4 * g + 1] = v[1]; x[4 * g + 2] = v[2]; x[4 * g + 3] = v[3];
+        } else if (vw == 2) {
+            f32x2 v0 = {0.f, 0.f}, v1 = {0.f, 0.f};
+            if (f0 < half) v0 = *reinterpret_cast<const f32x2*>(zr + col0);
+            if (f0 + 2 < half) v1 = *reinterpret_cast<const f32x2*>(zr + col0 + 2);
+            x[4 * g + 0] = v0[0]; x[4 * g + 1] = v0[1]; x[4 * g + 2] = v1[0]; x[4 * g + 3] = v1[1];
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) x[4 * g + j] = (f0 + j < half) ? zr[col0 + j] : 0.0f;
@@ -165,17 +173,20 @@ __device__ __forceinline__ f32x16 lsnf_load_tile(int t, const float* __restrict_
 }
 
 template <int HT>
-__device__ __forceinline__ void lsnf_store_tile(int t, const f32x16& x, float* __restrict__ zr, int half, int h, bool vec4) {
+__device__ __forceinline__ void lsnf_store_tile(int t, const f32x16& x, float* __restrict__ zr, int half, int h, int vw) {
     const int hh = t / HT, tt = t % HT;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int f0 = 32 * tt + 8 * g + 4 * h;
         const int col0 = hh * half + f0;
-        if (vec4) {
+        if (vw == 4) {
             if (f0 < half) {
                 f32x4 v = {x[4 * g + 0], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
                 *reinterpret_cast<f32x4*>(zr + col0) = v;
             }
+        } else if (vw == 2) {
+            if (f0 < half) { f32x2 v = {x[4 * g + 0], x[4 * g + 1]}; *reinterpret_cast<f32x2*>(zr + col0) = v; }
+            if (f0 + 2 < half) { f32x2 v = {x[4 * g + 2], x[4 * g + 3]}; *reinterpret_cast<f32x2*>(zr + col0 + 2) = v; }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -186,7 +197,7 @@ __device__ __forceinline__ void lsnf_store_tile(int t, const f32x16& x, float* _
 
 template <int HT>
 __device__ __forceinline__ void lsnf_load_rows(f32x16* x, const float* __restrict__ z, long row, int nz, int half,
-                                               int h, bool vec4) {
+                                               int h, int vec4) {
     const float* zr = z + row * (long)nz;
 #pragma unroll
     for (int t = 0; t < 2 * HT; ++t) x[t] = lsnf_load_tile<HT>(t, zr, half, h, vec4);
@@ -194,7 +205,7 @@ __device__ __forceinline__ void lsnf_load_rows(f32x16* x, const float* __restric
 
 template <int HT>
 __device__ __forceinline__ void lsnf_store_rows(const f32x16* x, float* __restrict__ z, long row, int nz, int half,
-                                                int h, bool vec4) {
+                                                int h, int vec4) {
     float* zr = z + row * (long)nz;
 #pragma unroll
     for (int t = 0; t < 2 * HT; ++t) lsnf_store_tile<HT>(t, x[t], zr, half, h, vec4);

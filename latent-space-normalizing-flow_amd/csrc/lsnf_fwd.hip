@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void lsnf_fwd_kernel(const FwdAr
         for (int r = 0; r < 16; ++r) x[t][r] = 0.001f * (float)(lane + r + t);
     float ell = 0.0f;
 #else
-    lsnf_load_rows<HT>(x, a.z_in, row, a.nz, a.half, h, a.vec4 != 0);
+    lsnf_load_rows<HT>(x, a.z_in, row, a.nz, a.half, h, a.vec4);
     float ell = a.objective ? a.objective[row] : 0.0f;
 #endif
 
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void lsnf_fwd_kernel(const FwdAr
         if (!more && live) {
             float* zo = a.z_out + sample * (long)a.nz;
 #pragma unroll
-            for (int t = 0; t < HT; ++t) lsnf_store_tile<HT>(t, v[t], zo, a.half, h, a.vec4 != 0);
+            for (int t = 0; t < HT; ++t) lsnf_store_tile<HT>(t, v[t], zo, a.half, h, a.vec4);
         }
         // logdet += sum(3*logs) (model.py:273-276); logdet += log|det W| (model.py:182,189)
         ell = ell + cb[32 * C::NP + 0];
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void lsnf_fwd_kernel(const FwdAr
         LSNF_STAMP(2 + 6 * blk + 4);
 
         if (a.z_saved != nullptr && more && live)
-            lsnf_store_rows<HT>(x, a.z_saved + (size_t)blk * a.B * a.nz, sample, a.nz, a.half, h, a.vec4 != 0);
+            lsnf_store_rows<HT>(x, a.z_saved + (size_t)blk * a.B * a.nz, sample, a.nz, a.half, h, a.vec4);
     }
 
     // ---- epilogue: z_out, logdet, ll = -0.5*sum z^2 + log(2pi) + logdet (train.py:317-319) ----
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void lsnf_fwd_kernel(const FwdAr
         {   // second half only: the first half went out during the last block
             float* zo = a.z_out + sample * (long)a.nz;
 #pragma unroll
-            for (int t = HT; t < NZT; ++t) lsnf_store_tile<HT>(t, x[t], zo, a.half, h, a.vec4 != 0);
+            for (int t = HT; t < NZT; ++t) lsnf_store_tile<HT>(t, x[t], zo, a.half, h, a.vec4);
         }
         if (h == 0) {
             a.logdet_out[sample] = ell;

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lsnf_rev_kernel(const RevArgs a) {
     const bool live = sample < a.B;
     const long row = live ? sample : (long)a.B - 1;
     f32x16 x[NZT];
-    lsnf_load_rows<HT>(x, a.z_in, row, a.nz, a.half, h, a.vec4 != 0);
+    lsnf_load_rows<HT>(x, a.z_in, row, a.nz, a.half, h, a.vec4);
     float obj = a.objective ? a.objective[row] : 0.0f;
 
     for (int blk = a.depth - 1; blk >= 0; --blk) {
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lsnf_rev_kernel(const RevArgs a) {
         obj = obj - cb[32 * C::NP + 0];   // logdet + (-1)*sum(3 logs)  (model.py:273-276)
     }
     if (live) {
-        lsnf_store_rows<HT>(x, a.z_out, sample, a.nz, a.half, h, a.vec4 != 0);
+        lsnf_store_rows<HT>(x, a.z_out, sample, a.nz, a.half, h, a.vec4);
         if (h == 0 && a.objective_out) a.objective_out[sample] = obj;
     }
 }

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(cons
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, m = lane & 31, h = lane >> 5;
-    const bool vec4 = a.vec4 != 0;
+    const int vec4 = a.vec4;
     auto T = [&](int t) { return tiles + (size_t)t * LSNF_TILE_FLOATS; };
 
     const int last = a.depth - 1;
@@ -183,12 +183,12 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(cons
         if (live && a.g_z_in) lsnf_store_tile<HT>(wave, g, a.g_z_in + sample * (long)a.nz, a.half, h, vec4);
         if (a.z_new) {
             const float coef = 0.5f * a.step * a.step;
-            const f32x16 zc = lsnf_load_tile<HT>(wave, a.z_cur + row * (long)a.nz, a.half, h, false);
+            const f32x16 zc = lsnf_load_tile<HT>(wave, a.z_cur + row * (long)a.nz, a.half, h, vec4);
             f32x16 gs = g;
 #pragma unroll
             for (int r = 0; r < 16; ++r) gf2 += g[r] * g[r];
             if (a.grad_g) {
-                const f32x16 gg = lsnf_load_tile<HT>(wave, a.grad_g + row * (long)a.nz, a.half, h, false);
+                const f32x16 gg = lsnf_load_tile<HT>(wave, a.grad_g + row * (long)a.nz, a.half, h, vec4);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { gg2 += gg[r] * gg[r]; gs[r] = gg[r] + g[r]; }
             }
@@ -196,11 +196,11 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) zn[r] = zc[r] - coef * gs[r];
             if (a.noise) {
-                const f32x16 nv = lsnf_load_tile<HT>(wave, a.noise + row * (long)a.nz, a.half, h, false);
+                const f32x16 nv = lsnf_load_tile<HT>(wave, a.noise + row * (long)a.nz, a.half, h, vec4);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) zn[r] = zn[r] + a.step * nv[r];
             }
-            if (live) lsnf_store_tile<HT>(wave, zn, a.z_new + sample * (long)a.nz, a.half, h, false);
+            if (live) lsnf_store_tile<HT>(wave, zn, a.z_new + sample * (long)a.nz, a.half, h, vec4);
         }
     }
     if (a.z_new && (a.gf_norm || a.gg_norm)) {      // kernel-uniform

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_fwd_kernel(cons
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, m = lane & 31, h = lane >> 5;
-    const bool vec4 = a.vec4 != 0;
+    const int vec4 = a.vec4;
 
     auto f1 = C::S1::fetch(a.panels, wave, lane);                   // first stage's weights in flight
     for (int i = tid; i < a.n_blocks * C::CONST_FLOATS; i += LSNF_WG_THREADS) cst[i] = a.consts[i];

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_rev_kernel(cons
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, m = lane & 31, h = lane >> 5;
-    const bool vec4 = a.vec4 != 0;
+    const int vec4 = a.vec4;
     auto T = [&](int t) { return tiles + (size_t)t * LSNF_TILE_FLOATS; };
 
     const int last = a.depth - 1;
