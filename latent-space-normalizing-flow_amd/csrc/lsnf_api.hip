@@ -74,7 +74,7 @@ int small_batch_max() {
 int geo_or_fail(LsnfGeo* g, int nz, int width, int depth, int coupling) {
     if (lsnf_geo_init(g, nz, width, depth, coupling))
         return fail(LSNF_E_GEOMETRY, "unsupported geometry nz=%d width=%d depth=%d coupling=%d "
-                    "(need nz even in [2,128], width in [1,128], depth in [1,%d], coupling 1)",
+                    "(need nz even in [2,128], width in [1,128], depth in [1,%d], coupling 0 or 1)",
                     nz, width, depth, coupling, LSNF_MAX_DEPTH);
     return 0;
 }
@@ -226,7 +226,7 @@ int lsnf_langevin_step(const float* plan, int nz, int width, int depth, int coup
 
 size_t lsnf_backward_params_workspace_floats(int nz, int width, int depth, int B) {
     LsnfGeo g;
-    if (lsnf_geo_init(&g, nz, width, depth, 1) || B < 0) return 0;
+    if (lsnf_geo_init(&g, nz, width, depth, 1) || B < 0) return 0;   // independent of the coupling type
     return lsnf_params_workspace_floats(nz, width, depth, B);
 }
 

@@ -58,6 +58,9 @@ static inline int lsnf_pick_tiles(int half, int width, int* HT, int* WT) {
     return -1;
 }
 
+// Additive coupling (coupling = 0, reference model.py:407-408: z2 = z2 + f(z1), f has nz/2 outputs) runs on the same
+// kernels: its pre-sigmoid panels are packed as zeros with bias +40, so that sigmoid = 1 and log sigmoid = 0 exactly
+// (the mechanism that already neutralises padded lanes); only the packing and un-folding differ.
 // Forward stages per block (affine coupling):
 //   S1  v  = Wa^T x + ca      K = NZT tiles, N = NZT tiles   (actnorm folded into the 1x1 "conv")
 //   S2  h1 = relu(W1'^T v1 + c1)   K = HT, N = WT
@@ -72,7 +75,7 @@ static inline int lsnf_pick_tiles(int half, int width, int* HT, int* WT) {
 //   B1  g_x  = Wa [g_v1; g_v2]      K = NZT,  N = NZT
 static inline int lsnf_geo_init(LsnfGeo* g, int nz, int width, int depth, int coupling) {
     if (nz < 2 || (nz & 1) || nz > 128 || width < 1 || width > 128 || depth < 1 || depth > LSNF_MAX_DEPTH) return -1;
-    if (coupling != 1) return -1;
+    if (coupling != 0 && coupling != 1) return -1;
     g->nz = nz; g->half = nz / 2; g->width = width; g->depth = depth; g->coupling = coupling;
     if (lsnf_pick_tiles(g->half, width, &g->HT, &g->WT)) return -1;
     g->NZT = 2 * g->HT;

@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void lsnf_tn_gemm_kernel(const TnArgs a) {
 
 // one workgroup per block: raw-parameter gradients from the folded ones
 __global__ __launch_bounds__(256) void lsnf_unfold_kernel(LsnfParamPtrs pp, LsnfGradPtrs gp, const float* fold_all,
-                                                          const float* gl_total, const float* winv_all, int nz, int width) {
+                                                          const float* gl_total, const float* winv_all, int nz, int width,
+                                                          int coupling) {
     const int blk = blockIdx.x, tid = threadIdx.x;
     const int half = nz / 2, w = width;
     const LsnfFoldLayout fl = lsnf_fold_layout(nz, width);
@@ -112,7 +113,8 @@ __global__ __launch_bounds__(256) void lsnf_unfold_kernel(LsnfParamPtrs pp, Lsnf
     const double Gtot = (double)gl_total[0];
     // exp(3*logs) of the four log-scale vectors, once (float64)
     __shared__ double ea[128], e1v[128], e2v[128], e3v[128];
-    for (int k = tid; k < nz; k += 256) { ea[k] = exp((double)(P[P_ALOGS][k] * 3.0f)); e3v[k] = exp((double)(P[P_LOGS3][k] * 3.0f)); }
+    const int n3 = coupling ? nz : half;           // fc_zeros outputs: interleaved shift/scale columns, or shift only
+    for (int k = tid; k < nz; k += 256) { ea[k] = exp((double)(P[P_ALOGS][k] * 3.0f)); if (k < n3) e3v[k] = exp((double)(P[P_LOGS3][k] * 3.0f)); }
     for (int k = tid; k < w; k += 256) { e1v[k] = exp((double)(P[P_LOGS1][k] * 3.0f)); e2v[k] = exp((double)(P[P_LOGS2][k] * 3.0f)); }
     __syncthreads();
     // ---- actnorm + 1x1 conv:  Wa = diag(e) W, ca = (b*e) W, const = 3*sum(s) + log|det W|
@@ -151,19 +153,20 @@ __global__ __launch_bounds__(256) void lsnf_unfold_kernel(LsnfParamPtrs pp, Lsnf
                 Gp[iw][idx] = (float)((double)F[oW + idx] * ev[n]);
             }
     }
-    // ---- fc_zeros: column c = 2f + which (shift / pre-sigmoid interleaved, model.py:411-413)
-    for (int c = tid; c < nz; c += 256) {
-        const int f = c >> 1, which = c & 1;
+    // ---- fc_zeros: affine: column c = 2f + which (shift / pre-sigmoid interleaved, model.py:411-413);
+    //      additive (model.py:407-408): column c = f, shift only
+    for (int c = tid; c < n3; c += 256) {
+        const int f = coupling ? (c >> 1) : c, which = coupling ? (c & 1) : 0;
         const int oW = which ? fl.dW3p : fl.dW3s, oc = which ? fl.dc3p : fl.dc3s;
         const double e = e3v[c], b = (double)P[P_B3][c], dc = (double)F[oc + f];
         double u = 0.0;
-        for (int k = 0; k < w; ++k) u += (double)P[P_W3][k * nz + c] * (double)F[oW + k * half + f];
+        for (int k = 0; k < w; ++k) u += (double)P[P_W3][k * n3 + c] * (double)F[oW + k * half + f];
         if (Gp[P_B3]) Gp[P_B3][c] = (float)(dc * e);
         if (Gp[P_LOGS3]) Gp[P_LOGS3][c] = (float)(3.0 * e * (u + b * dc));
     }
     if (Gp[P_W3])
-        for (int idx = tid; idx < w * nz; idx += 256) {
-            const int k = idx / nz, c = idx % nz, f = c >> 1, which = c & 1;
+        for (int idx = tid; idx < w * n3; idx += 256) {
+            const int k = idx / n3, c = idx % n3, f = coupling ? (c >> 1) : c, which = coupling ? (c & 1) : 0;
             const int oW = which ? fl.dW3p : fl.dW3s;
             Gp[P_W3][idx] = (float)((double)F[oW + k * half + f] * e3v[c]);
         }
@@ -196,6 +199,6 @@ hipError_t lsnf_launch_backward_params(const LsnfGeo& g, const float* plan, cons
         gp.p[i] = i < g.depth * 12 ? grads_host[i] : nullptr;
     }
     hipLaunchKernelGGL(lsnf_unfold_kernel, dim3(g.depth), dim3(256), 0, stream, pp, gp, (const float*)fold,
-                       (const float*)gl_total, plan + g.off_winv, g.nz, g.width);
+                       (const float*)gl_total, plan + g.off_winv, g.nz, g.width, g.coupling);
     return hipGetLastError();
 }

@@ -193,6 +193,10 @@ __device__ static double fwd_mat(const LsnfGeo& g, const float* const* P, int st
     default: {  // 4: n in [0,32HT) -> shift column 2f ; [32HT,64HT) -> pre-sigmoid column 2f+1
         const int which = n / (32 * HT), f = n % (32 * HT);
         if (k >= w || f >= half) return 0.0;
+        if (g.coupling == 0) {   // additive: fc_zeros is (w, nz/2), all shift; no scale path
+            if (which) return 0.0;
+            return (double)P[P_W3][k * half + f] * e3(P[P_LOGS3], f);
+        }
         const int col = 2 * f + which;
         return (double)P[P_W3][k * nz + col] * e3(P[P_LOGS3], col);
     }
@@ -214,6 +218,7 @@ __device__ static double fwd_bias(const LsnfGeo& g, const float* const* P, int s
     default: {
         const int which = n / (32 * HT), f = n % (32 * HT);
         if (f >= half) return which ? 40.0 : 0.0;   // padded scale lane: sigmoid(40) == 1, log == 0
+        if (g.coupling == 0) return which ? 40.0 : (double)P[P_B3][f] * e3(P[P_LOGS3], f);
         const int col = 2 * f + which;
         return (double)P[P_B3][col] * e3(P[P_LOGS3], col) + (which ? 2.0 : 0.0);   // "+ 2." model.py:413
     }

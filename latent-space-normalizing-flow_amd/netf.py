@@ -81,8 +81,7 @@ class revnet2d_step(nn.Module):
         if hps.f_flow_coupling == 1:
             self.f = f(hps.f_width, nz // 2, nz)
         elif hps.f_flow_coupling == 0:
-            raise NotImplementedError("additive coupling (f_flow_coupling=0) has no HIP kernel yet; the reference "
-                                      "default and every published config use the affine coupling (=1)")
+            self.f = f(hps.f_width, nz // 2, nz // 2)      # additive coupling: shift only (model.py:385,407-408)
         else:
             raise Exception()
 

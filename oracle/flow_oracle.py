@@ -97,8 +97,15 @@ def mlp_f(p: Params, pre: str, z1: Tensor) -> Tensor:
     return h
 
 
-def block_fwd(p: Params, i: int, z: Tensor, logdet: Tensor, coupling: int = 1):
+def coupling_of(p: Params) -> int:
+    """1 = affine (fc_zeros has nz outputs, model.py:387), 0 = additive (nz/2 outputs, model.py:385)."""
+    pre = block_prefix(0)
+    return 1 if p[pre + "f.fc_zeros.w"].shape[1] == p[pre + "actnorm.logs"].shape[1] else 0
+
+
+def block_fwd(p: Params, i: int, z: Tensor, logdet: Tensor, coupling: int | None = None):
     """One revnet2d_step, forward branch: model.py:391-422 (permutation 2)."""
+    coupling = coupling_of(p) if coupling is None else coupling
     pre = block_prefix(i)
     n_z = z.shape[-1]
     z, logdet = actnorm_fwd(z, p[pre + "actnorm.b"], p[pre + "actnorm.logs"], logdet)  # :392
@@ -121,9 +128,10 @@ def block_fwd(p: Params, i: int, z: Tensor, logdet: Tensor, coupling: int = 1):
     return z, logdet
 
 
-def block_rev(p: Params, i: int, z: Tensor, logdet: Tensor, coupling: int = 1):
+def block_rev(p: Params, i: int, z: Tensor, logdet: Tensor, coupling: int | None = None):
     """One revnet2d_step, reverse branch: model.py:424-456.  Functional (the reference
     mutates its inputs in place, model.py:436-438; values are identical)."""
+    coupling = coupling_of(p) if coupling is None else coupling
     pre = block_prefix(i)
     n_z = z.shape[-1]
     z1 = z[:, : n_z // 2]
@@ -149,7 +157,7 @@ def block_rev(p: Params, i: int, z: Tensor, logdet: Tensor, coupling: int = 1):
 # ----------------------------------------------------------------------------------
 # the stack (= _netF.forward for f_n_levels == 1)
 # ----------------------------------------------------------------------------------
-def flow_forward(p: Params, z: Tensor, objective: Tensor, coupling: int = 1,
+def flow_forward(p: Params, z: Tensor, objective: Tensor, coupling: int | None = None,
                  first_block: int = 0, n_blocks: int | None = None):
     """_netF.forward(reverse=False): model.py:474-483 -> revnet2d :358-360."""
     d = depth_of(p)
@@ -159,7 +167,7 @@ def flow_forward(p: Params, z: Tensor, objective: Tensor, coupling: int = 1,
     return z, objective
 
 
-def flow_reverse(p: Params, z: Tensor, objective: Tensor, coupling: int = 1):
+def flow_reverse(p: Params, z: Tensor, objective: Tensor, coupling: int | None = None):
     """_netF.forward(reverse=True, return_obj=True): model.py:485-498.
     Returns (z, -objective) exactly like the reference does with return_obj=True."""
     d = depth_of(p)
@@ -175,12 +183,12 @@ def log_prob(z1: Tensor, logdet: Tensor) -> Tensor:
     return prior_ll + logdet
 
 
-def flow_log_prob(p: Params, z: Tensor, coupling: int = 1):
+def flow_log_prob(p: Params, z: Tensor, coupling: int | None = None):
     z1, logdet = flow_forward(p, z, torch.zeros(z.shape[0], dtype=z.dtype), coupling)
     return z1, logdet, log_prob(z1, logdet)
 
 
-def grad_neg_sum_ll_wrt_z(p: Params, z: Tensor, coupling: int = 1) -> Tensor:
+def grad_neg_sum_ll_wrt_z(p: Params, z: Tensor, coupling: int | None = None) -> Tensor:
     """train.py:316-323: d(-sum_b ll)/dz by autograd over the restated ops."""
     zz = z.clone().detach().requires_grad_(True)
     _, _, ll = flow_log_prob(p, zz, coupling)
@@ -188,7 +196,7 @@ def grad_neg_sum_ll_wrt_z(p: Params, z: Tensor, coupling: int = 1) -> Tensor:
     return g
 
 
-def grad_neg_mean_ll_wrt_params(p: Params, z: Tensor, coupling: int = 1) -> Dict[str, Tensor]:
+def grad_neg_mean_ll_wrt_params(p: Params, z: Tensor, coupling: int | None = None) -> Dict[str, Tensor]:
     """train.py:406-411: d(-mean_b ll)/dtheta for every parameter that receives a gradient
     (the fc_*.b tensors never do; the duplicate 'actnorm.bias' key aliases 'actnorm.b')."""
     live = {k: v.clone().detach().requires_grad_(True) for k, v in p.items() if is_live_param(k)}

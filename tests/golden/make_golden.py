@@ -32,12 +32,12 @@ def hps_for(width, depth=5, coupling=1):
                                  f_width=width, f_flow_coupling=coupling)
 
 
-def build_netF(nz, width, seed, fcz_std, all_std, depth=5):
+def build_netF(nz, width, seed, fcz_std, all_std, depth=5, coupling=1):
     """Reference init under fixed seeds (W init uses numpy QR, model.py:176), then the
     perturbations SURVEY 8c prescribes so that the coupling is non-trivial."""
     torch.manual_seed(seed)
     np.random.seed(seed)
-    net = ref._netF(hps_for(width, depth), nz=nz)
+    net = ref._netF(hps_for(width, depth, coupling), nz=nz)
     g = torch.Generator().manual_seed(seed + 1000)
     with torch.no_grad():
         for name, prm in net.named_parameters():
@@ -59,14 +59,14 @@ def ll_of(z1, logdet):
     return prior_ll + logdet                                        # train.py:319
 
 
-def run_case(name, nz, width, B, sigma_z, seed, fcz_std=0.05, all_std=0.0, with_param_grads=True):
-    net = build_netF(nz, width, seed, fcz_std, all_std)
+def run_case(name, nz, width, B, sigma_z, seed, fcz_std=0.05, all_std=0.0, with_param_grads=True, coupling=1):
+    net = build_netF(nz, width, seed, fcz_std, all_std, coupling=coupling)
     g = torch.Generator().manual_seed(seed + 77)
     z = (sigma_z * torch.randn(B, nz, generator=g)).float()
     obj0 = torch.zeros(B)
 
     out = {"meta_nz": np.int64(nz), "meta_width": np.int64(width), "meta_depth": np.int64(5),
-           "meta_B": np.int64(B), "z": z.numpy().copy()}
+           "meta_B": np.int64(B), "meta_coupling": np.int64(coupling), "z": z.numpy().copy()}
     for k, v in net.state_dict().items():
         if k.endswith(".bias"):      # alias of '.b' (model.py:231); re-created on load
             continue
@@ -110,7 +110,7 @@ def run_case(name, nz, width, B, sigma_z, seed, fcz_std=0.05, all_std=0.0, with_
         out["block_logdet"] = np.stack(ls)
 
     # fp64 tie-breaker: the same module in double
-    net64 = build_netF(nz, width, seed, fcz_std, all_std).double()
+    net64 = build_netF(nz, width, seed, fcz_std, all_std, coupling=coupling).double()
     with torch.no_grad():
         z1d, ldd, _ = net64(z.double(), objective=torch.zeros(B, dtype=torch.float64))
         out["ll_f64"] = ll_of(z1d, ldd).numpy().copy()
@@ -179,7 +179,7 @@ def run_langevin(name, nz=100, width=64, B=16, K=3, ngf=8, seed=5):
     print(f"{name}: K={K} f_log_lkhd={f_l} -> {os.path.getsize(path) / 1e6:.2f} MB")
 
 
-if __name__ == "__main__":
+def affine_cases():
     # tiny (all kernels' padding paths), odd B
     run_case("tiny_nz8_w4_B7", 8, 4, 7, 1.0, seed=11)
     run_case("tiny_nz8_w4_B37_trained", 8, 4, 37, 1.0, seed=12, fcz_std=0.1, all_std=0.1)
@@ -193,3 +193,17 @@ if __name__ == "__main__":
     run_case("c5_nz100_w128_B100", 100, 128, 100, 1.0, seed=3)
     # caller harness: noise-free Langevin trajectory
     run_langevin("langevin_nz100_w64_B16_K3")
+
+
+def additive_cases():
+    # additive coupling, f_flow_coupling=0 (model.py:385,407-408,429-430)
+    run_case("additive_nz20_w12_B33", 20, 12, 33, 1.0, seed=21, coupling=0)
+    run_case("additive_nz100_w64_B50", 100, 64, 50, 1.0, seed=22, coupling=0)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["affine", "additive"]      # `make_golden.py additive` rewrites only that group
+    if "affine" in which:
+        affine_cases()
+    if "additive" in which:
+        additive_cases()

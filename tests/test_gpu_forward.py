@@ -15,7 +15,7 @@ Z_ABS = 1e-4
 
 def _plan(lsnf, p, g, dev):
     nz, w, d = int(g["meta_nz"]), int(g["meta_width"]), int(g["meta_depth"])
-    return lsnf.prepare(lsnf.params_from_state_dict(p, d, dev), nz, w, d), nz, w, d
+    return lsnf.prepare(lsnf.params_from_state_dict(p, d, dev), nz, w, d, int(g.get("meta_coupling", 1))), nz, w, d
 
 
 @pytest.fixture(scope="module")

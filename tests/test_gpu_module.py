@@ -15,7 +15,8 @@ KINK = 2e-6
 
 def make_net(lsnf, p, g, dev):
     nz, w, d = int(g["meta_nz"]), int(g["meta_width"]), int(g["meta_depth"])
-    hps = types.SimpleNamespace(f_n_levels=1, f_depth=d, f_flow_permutation=2, f_width=w, f_flow_coupling=1)
+    hps = types.SimpleNamespace(f_n_levels=1, f_depth=d, f_flow_permutation=2, f_width=w,
+                                f_flow_coupling=int(g.get("meta_coupling", 1)))
     net = lsnf._netF(hps, nz=nz)
     net.load_state_dict(p, strict=True)
     return net.to(dev), nz

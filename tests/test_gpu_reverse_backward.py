@@ -20,7 +20,7 @@ def lsnf():
 
 def _plan(lsnf, p, g, dev):
     nz, w, d = int(g["meta_nz"]), int(g["meta_width"]), int(g["meta_depth"])
-    return lsnf.prepare(lsnf.params_from_state_dict(p, d, dev), nz, w, d)
+    return lsnf.prepare(lsnf.params_from_state_dict(p, d, dev), nz, w, d, int(g.get("meta_coupling", 1)))
 
 
 @pytest.mark.parametrize("name", golden_names())

@@ -55,8 +55,8 @@ def test_constructor_errors_mirror_reference():
         lsnf_amd._netF(hps(levels=2), nz=8)                   # model.py:467-470
     with pytest.raises(Exception):
         lsnf_amd._netF(hps(perm=0), nz=8)                     # model.py:378-379
-    with pytest.raises(NotImplementedError):
-        lsnf_amd._netF(hps(coupling=0), nz=8)
+    add = lsnf_amd._netF(hps(coupling=0), nz=8)             # additive coupling: fc_zeros has nz/2 outputs (model.py:385)
+    assert add.state_dict()[O.block_prefix(0) + "f.fc_zeros.w"].shape == (64, 4)
 
 
 def test_cpu_call_fails_loudly_no_fallback():
@@ -99,4 +99,5 @@ def test_geometry_queries_need_no_gpu():
     assert lib.lsnf_plan_floats(128, 64, 5, 1) > 5 * 32768
     assert lib.lsnf_plan_floats(130, 64, 5, 1) == 0 and lib.lsnf_plan_floats(7, 4, 5, 1) == 0
     assert lib.lsnf_plan_floats(128, 64, 17, 1) == 0
+    assert lib.lsnf_plan_floats(128, 64, 5, 0) == lib.lsnf_plan_floats(128, 64, 5, 1) and lib.lsnf_plan_floats(128, 64, 5, 2) == 0
     assert lib.lsnf_backward_params_workspace_floats(128, 64, 5, 100) > 0
