@@ -70,8 +70,10 @@ __device__ __forceinline__ void store_plain(const f32x16* x, float* __restrict__
 }
 
 // NW waves per workgroup (4: two workgroups per CU, 8: one; see lsnf_fwd.hip)
+// Wide MLPs (WT = 4, e.g. f_width = 128) need ~300 live VGPRs in the backward: give them the whole register file
+// (one wave per SIMD) instead of spilling 80-110 registers to scratch at two waves per SIMD.
 template <class C, bool DUMP, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void lsnf_bwd_z_kernel(const BwdArgs a) {
+__global__ __launch_bounds__(64 * NW, (C::WT >= 4 ? 1 : 2)) void lsnf_bwd_z_kernel(const BwdArgs a) {
     constexpr int HT = C::HT, WT = C::WT, NZT = C::NZT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* cst = smem;                                   // depth * CONST_USED
@@ -266,12 +268,8 @@ template <class C, bool DUMP, int NW>
 hipError_t launch_bwd_w(const BwdArgs& a, hipStream_t stream) {
     const size_t lds = ((size_t)a.depth * C::CONST_USED + 2 * (size_t)C::SLOT) * sizeof(float);
     auto kern = lsnf_bwd_z_kernel<C, DUMP, NW>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static unsigned long long lds_ok = 0;
+    if (hipError_t e = lsnf_allow_big_lds((const void*)kern, &lds_ok); e != hipSuccess) return e;
     const unsigned grid = (unsigned)((a.B + 32 * NW - 1) / (32 * NW));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, a);
     return hipGetLastError();

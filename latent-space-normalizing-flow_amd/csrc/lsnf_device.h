@@ -15,6 +15,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LSNF_AS1 __attribute__((address_space(1)))
 #define LSNF_AS3 __attribute__((address_space(3)))
 
+// Host side: kernels that use more than 64 KiB of dynamic LDS need the attribute set once PER DEVICE of the process.
+static inline hipError_t lsnf_allow_big_lds(const void* kernel, unsigned long long* done_mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && ((*done_mask >> dev) & 1ull)) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64) *done_mask |= 1ull << dev;      // benign race: the call is idempotent
+    return hipSuccess;
+}
+
 // feature offset inside a 32-tile of accumulator register r on lane-half h
 __device__ __forceinline__ constexpr int lsnf_feat(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 

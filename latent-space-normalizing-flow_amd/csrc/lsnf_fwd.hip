@@ -228,12 +228,8 @@ template <class C, int FWD_WAVES>
 hipError_t launch_fwd_w(const FwdArgs& a, hipStream_t stream) {
     const size_t lds = ((size_t)a.n_blocks * C::CONST_FLOATS + 2 * (size_t)C::SLOT) * sizeof(float);
     auto kern = lsnf_fwd_kernel<C, FWD_WAVES>;
-    static bool attr_set = false;  // benign race: idempotent
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static unsigned long long lds_ok = 0;
+    if (hipError_t e = lsnf_allow_big_lds((const void*)kern, &lds_ok); e != hipSuccess) return e;
     const unsigned grid = (unsigned)((a.B + 32 * FWD_WAVES - 1) / (32 * FWD_WAVES));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * FWD_WAVES), lds, stream, a);
     return hipGetLastError();

@@ -124,12 +124,8 @@ template <class C, int NW>
 hipError_t launch_rev_w(const RevArgs& a, hipStream_t stream) {
     const size_t lds = ((size_t)a.depth * C::CONST_PER_BLOCK + 2 * (size_t)C::SLOT) * sizeof(float);
     auto kern = lsnf_rev_kernel<C, NW>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static unsigned long long lds_ok = 0;
+    if (hipError_t e = lsnf_allow_big_lds((const void*)kern, &lds_ok); e != hipSuccess) return e;
     const unsigned grid = (unsigned)((a.B + 32 * NW - 1) / (32 * NW));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, a);
     return hipGetLastError();

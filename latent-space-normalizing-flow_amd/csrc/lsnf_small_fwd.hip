@@ -188,12 +188,8 @@ hipError_t launch_small_fwd(const SmallFwdArgs& a, hipStream_t stream) {
     const size_t lds = ((size_t)C::T_END * LSNF_TILE_FLOATS + C::AUX_FLOATS + (size_t)a.n_blocks * C::CONST_FLOATS) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = lsnf_small_fwd_kernel<C>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static unsigned long long lds_ok = 0;
+    if (hipError_t e = lsnf_allow_big_lds((const void*)kern, &lds_ok); e != hipSuccess) return e;
     const unsigned grid = (unsigned)((a.B + LSNF_SMALL_SAMPLES - 1) / LSNF_SMALL_SAMPLES);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(LSNF_WG_THREADS), lds, stream, a);
     return hipGetLastError();
