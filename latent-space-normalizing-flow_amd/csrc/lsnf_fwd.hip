@@ -12,6 +12,7 @@
 // directly the next GEMM's B operand (lsnf_layout.h).  Weights stream L2 -> LDS by LDS-DMA in
 // panel pairs (two n-tiles x all k-tiles, <= 32 KiB, two independent accumulator chains), double-buffered,
 // one barrier per pair.
+#include <stdlib.h>
 #include "lsnf_device.h"
 
 namespace {
@@ -238,7 +239,10 @@ hipError_t launch_fwd_w(const FwdArgs& a, hipStream_t stream) {
 template <class C>
 hipError_t launch_fwd(const FwdArgs& a, hipStream_t stream) {
     // more than 256 four-wave workgroups would double up on CUs anyway: switch to one eight-wave workgroup per CU
-    return a.B > 256 * 128 ? launch_fwd_w<C, 8>(a, stream) : launch_fwd_w<C, 4>(a, stream);
+    static int forced = -1;                       // LSNF_FWD_WAVES=4|8: developer override for A/B runs
+    if (forced < 0) { const char* e = getenv("LSNF_FWD_WAVES"); forced = e ? atoi(e) : 0; }
+    const bool wide = forced ? forced == 8 : a.B > 256 * 128;
+    return wide ? launch_fwd_w<C, 8>(a, stream) : launch_fwd_w<C, 4>(a, stream);
 }
 }  // namespace
 
