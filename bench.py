@@ -220,7 +220,7 @@ def main():
                        "prepare_ms_not_in_step": prep_ms},
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel": "lsnf_fwd_kernel<FwdCfg<2,2>>", "kernel_ms": kern_ms,
+                         "kernel": "lsnf_fwd_kernel<FwdCfg<2,2>, 8>", "kernel_ms": kern_ms,
                          "flop_per_launch": FLOP_PER_SAMPLE * B_PER_GPU,
                          "hbm_frac_secondary": BYTES_PER_SAMPLE_FUSED * B_PER_GPU / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
         }
