@@ -13,24 +13,10 @@
 namespace {
 
 template <int HT_, int WT_>
-struct BwdCfg {
-    static constexpr int HT = HT_, WT = WT_, NZT = 2 * HT_;
-    static constexpr int P1 = NZT, P2 = WT, P3 = WT, P4 = 2 * HT, NP = P1 + P2 + P3 + P4;
-    static constexpr int MAXKT = (NZT > WT ? NZT : WT);
-    static constexpr int SLOT = MAXKT * LSNF_FRAG_FLOATS;
-    static constexpr int FWD_BLOCK = LSNF_FRAG_FLOATS * (NZT * NZT + WT * HT + WT * WT + 2 * HT * WT);
-    static constexpr int FWD_CONST = 32 * NP + 32;
-    static constexpr int OFF_S2 = LSNF_FRAG_FLOATS * NZT * NZT;
-    static constexpr int OFF_S3 = OFF_S2 + LSNF_FRAG_FLOATS * WT * HT;
-    static constexpr int OFF_S4 = OFF_S3 + LSNF_FRAG_FLOATS * WT * WT;
-    // backward stream of one block: B4 (WT panels, KT=2HT), B3 (WT, KT=WT), B2 (HT, KT=WT), B1 (NZT, KT=NZT)
-    static constexpr int BWD_BLOCK = LSNF_FRAG_FLOATS * (WT * 2 * HT + WT * WT + HT * WT + NZT * NZT);
-    static constexpr int OFF_B4 = 0;
-    static constexpr int OFF_B3 = OFF_B4 + LSNF_FRAG_FLOATS * WT * 2 * HT;
-    static constexpr int OFF_B2 = OFF_B3 + LSNF_FRAG_FLOATS * WT * WT;
-    static constexpr int OFF_B1 = OFF_B2 + LSNF_FRAG_FLOATS * HT * WT;
-    // only the MLP biases are needed: S2, S3, S4 bias blocks
-    static constexpr int CONST_USED = 32 * (P2 + P3 + P4);
+struct BwdCfg : LsnfStackCfg<HT_, WT_> {
+    using S = LsnfStackCfg<HT_, WT_>;
+    using S::HT; using S::WT; using S::NZT;
+    static constexpr int CONST_USED = 32 * (S::P2 + S::P3 + S::P4);   // only the MLP biases are needed: S2, S3, S4 bias blocks
 };
 
 struct BwdArgs {

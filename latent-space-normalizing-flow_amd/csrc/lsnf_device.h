@@ -27,6 +27,52 @@ static inline hipError_t lsnf_allow_big_lds(const void* kernel, unsigned long lo
     return hipSuccess;
 }
 
+// Compile-time geometry of one coupling block for a kernel instantiation (HT = tiles of nz/2, WT = tiles of f_width):
+// panel counts / k-tiles of the forward stages S1..S4 and of the backward stages B4..B1, and the float offsets of
+// their packed panels inside a block's forward / backward stream (layout produced by lsnf_prep.hip).
+template <int HT_, int WT_>
+struct LsnfStackCfg {
+    static constexpr int HT = HT_, WT = WT_, NZT = 2 * HT_;
+    static constexpr int P1 = NZT, P2 = WT, P3 = WT, P4 = 2 * HT, NP = P1 + P2 + P3 + P4;   // n-tiles per forward stage
+    static constexpr int KT1 = NZT, KT2 = HT, KT3 = WT, KT4 = WT;
+    static constexpr int OFF_S2 = LSNF_FRAG_FLOATS * P1 * KT1;
+    static constexpr int OFF_S3 = OFF_S2 + LSNF_FRAG_FLOATS * P2 * KT2;
+    static constexpr int OFF_S4 = OFF_S3 + LSNF_FRAG_FLOATS * P3 * KT3;
+    static constexpr int FWD_BLOCK = OFF_S4 + LSNF_FRAG_FLOATS * P4 * KT4;
+    static constexpr int FWD_CONST = 32 * NP + 32;             // biases of S1..S4, then [sum 3 logs, log|det W|, pad]
+    static constexpr int INV_BLOCK = LSNF_FRAG_FLOATS * NZT * NZT;
+    static constexpr int INV_CONST = 32 * NZT;
+    static constexpr int OFF_B4 = 0;
+    static constexpr int OFF_B3 = OFF_B4 + LSNF_FRAG_FLOATS * WT * 2 * HT;
+    static constexpr int OFF_B2 = OFF_B3 + LSNF_FRAG_FLOATS * WT * WT;
+    static constexpr int OFF_B1 = OFF_B2 + LSNF_FRAG_FLOATS * HT * WT;
+    static constexpr int BWD_BLOCK = OFF_B1 + LSNF_FRAG_FLOATS * NZT * NZT;
+    static constexpr int MAXKT = (NZT > WT ? NZT : WT);
+    static constexpr int SLOT = 2 * MAXKT * LSNF_FRAG_FLOATS;  // LDS floats of one panel PAIR (throughput kernels)
+};
+
+// In-kernel batch sums (stats argument of lsnf_forward): called by ONE lane per workgroup with the workgroup's partial
+// sums.  Returning atomics: their values come back only after the adds have been performed at the memory side, and the
+// ticket increment is made to depend on them -- ordering without an L2 write-back fence (a release fence here would
+// flush this workgroup's freshly written z_out lines: +2..6 us per workgroup).  The workgroup that draws the last
+// ticket reads the totals with atomic read-modify-writes (a plain or sc1 load could be served by this XCD's L2, which
+// is not coherent with the other XCDs), publishes them and re-arms the accumulators for the next launch.
+__device__ __forceinline__ void lsnf_publish_stats(double* stats, double sum_ll, double sum_logdet, int rows) {
+    const double r0 = atomicAdd(&stats[0], sum_ll);
+    const double r1 = atomicAdd(&stats[1], sum_logdet);
+    unsigned long long inc = 1ull;
+    asm volatile("" : "+v"(inc) : "v"(r0), "v"(r1));
+    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(&stats[2]);
+    const unsigned long long t = atomicAdd(ticket, inc);
+    if (t == (unsigned long long)gridDim.x - 1) {
+        const double fl = atomicAdd(&stats[0], 0.0);
+        const double fd = atomicAdd(&stats[1], 0.0);
+        stats[4] = fl; stats[5] = fd; stats[6] = (double)rows;
+        atomicAdd(&stats[0], -fl); atomicAdd(&stats[1], -fd);      // fire and forget
+        atomicExch(ticket, 0ull);
+    }
+}
+
 // feature offset inside a 32-tile of accumulator register r on lane-half h
 __device__ __forceinline__ constexpr int lsnf_feat(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 

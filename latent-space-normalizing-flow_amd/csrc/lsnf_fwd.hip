@@ -18,18 +18,9 @@
 namespace {
 
 template <int HT_, int WT_>
-struct FwdCfg {
-    static constexpr int HT = HT_, WT = WT_, NZT = 2 * HT_;
-    static constexpr int P1 = NZT, P2 = WT, P3 = WT, P4 = 2 * HT;  // n-tiles (single panels) per stage
-    static constexpr int NP = P1 + P2 + P3 + P4;
-    static constexpr int KT1 = NZT, KT2 = HT, KT3 = WT, KT4 = WT;
-    static constexpr int MAXKT = (NZT > WT ? NZT : WT);
-    static constexpr int SLOT = 2 * MAXKT * LSNF_FRAG_FLOATS;      // a panel PAIR
-    static constexpr int OFF_S2 = LSNF_FRAG_FLOATS * P1 * KT1;
-    static constexpr int OFF_S3 = OFF_S2 + LSNF_FRAG_FLOATS * P2 * KT2;
-    static constexpr int OFF_S4 = OFF_S3 + LSNF_FRAG_FLOATS * P3 * KT3;
-    static constexpr int BLOCK_FLOATS = OFF_S4 + LSNF_FRAG_FLOATS * P4 * KT4;
-    static constexpr int CONST_FLOATS = 32 * NP + 32;
+struct FwdCfg : LsnfStackCfg<HT_, WT_> {
+    using B = LsnfStackCfg<HT_, WT_>;
+    static constexpr int BLOCK_FLOATS = B::FWD_BLOCK, CONST_FLOATS = B::FWD_CONST;
 };
 
 struct FwdArgs {
@@ -197,26 +188,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void lsnf_fwd_kernel(const FwdAr
         if (tid == 0) {
             double tl = 0.0, td = 0.0;
             for (int w = 0; w < FWD_WAVES; ++w) { tl += red[2 * w]; td += red[2 * w + 1]; }
-            // Returning atomics: their values come back only after the adds have been performed at the memory
-            // side, and the ticket increment is made to depend on them -- ordering without an L2 write-back fence
-            // (a release fence here would flush this workgroup's freshly written z_out lines: +2..6 us per WG).
-            const double r0 = atomicAdd(&a.stats[0], tl);
-            const double r1 = atomicAdd(&a.stats[1], td);
-            unsigned long long inc = 1ull;
-            asm volatile("" : "+v"(inc) : "v"(r0), "v"(r1));
-            unsigned long long* ticket = reinterpret_cast<unsigned long long*>(&a.stats[2]);
-            const unsigned long long t = atomicAdd(ticket, inc);
-            if (t == (unsigned long long)gridDim.x - 1) {   // last workgroup: publish and re-arm for the next launch
-// every other workgroup's adds were performed before its ticket.  The totals are read with atomic
-                // read-modify-writes (performed at the memory side like the adds: a plain or sc1 load could be served
-                // by this XCD's L2, which is not coherent with the other XCDs); the two reads are independent, so
-                // they cost one round trip; the re-arming atomics are fire-and-forget.
-                const double fl = atomicAdd(&a.stats[0], 0.0);
-                const double fd = atomicAdd(&a.stats[1], 0.0);
-                a.stats[4] = fl; a.stats[5] = fd; a.stats[6] = (double)a.B;
-                atomicAdd(&a.stats[0], -fl); atomicAdd(&a.stats[1], -fd);
-                atomicExch(ticket, 0ull);
-            }
+            lsnf_publish_stats(a.stats, tl, td, a.B);
         }
     }
     LSNF_STAMP(40);

@@ -9,19 +9,10 @@
 namespace {
 
 template <int HT_, int WT_>
-struct RevCfg {
-    static constexpr int HT = HT_, WT = WT_, NZT = 2 * HT_;
-    static constexpr int P1 = NZT, P2 = WT, P3 = WT, P4 = 2 * HT, NP = P1 + P2 + P3 + P4;
-    static constexpr int MAXKT = (NZT > WT ? NZT : WT);
-    static constexpr int SLOT = MAXKT * LSNF_FRAG_FLOATS;
-    static constexpr int FWD_BLOCK = LSNF_FRAG_FLOATS * (NZT * NZT + WT * HT + WT * WT + 2 * HT * WT);
-    static constexpr int FWD_CONST = 32 * NP + 32;
-    static constexpr int INV_BLOCK = LSNF_FRAG_FLOATS * NZT * NZT;
-    static constexpr int INV_CONST = 32 * NZT;
-    static constexpr int OFF_S2 = LSNF_FRAG_FLOATS * NZT * NZT;
-    static constexpr int OFF_S3 = OFF_S2 + LSNF_FRAG_FLOATS * WT * HT;
-    static constexpr int OFF_S4 = OFF_S3 + LSNF_FRAG_FLOATS * WT * WT;
-    static constexpr int CONST_PER_BLOCK = FWD_CONST + INV_CONST;
+struct RevCfg : LsnfStackCfg<HT_, WT_> {
+    using S = LsnfStackCfg<HT_, WT_>;
+    using S::HT; using S::WT; using S::NZT;
+    static constexpr int CONST_PER_BLOCK = S::FWD_CONST + S::INV_CONST;
 };
 
 struct RevArgs {

@@ -7,14 +7,10 @@
 namespace {
 
 template <int HT_, int WT_>
-struct SmallFwdCfg {
-    static constexpr int HT = HT_, WT = WT_, NZT = 2 * HT_;
-    static constexpr int P1 = NZT, P2 = WT, P3 = WT, P4 = 2 * HT, NP = P1 + P2 + P3 + P4;
-    static constexpr int OFF_S2 = LSNF_FRAG_FLOATS * NZT * NZT;
-    static constexpr int OFF_S3 = OFF_S2 + LSNF_FRAG_FLOATS * WT * HT;
-    static constexpr int OFF_S4 = OFF_S3 + LSNF_FRAG_FLOATS * WT * WT;
-    static constexpr int BLOCK_FLOATS = OFF_S4 + LSNF_FRAG_FLOATS * 2 * HT * WT;
-    static constexpr int CONST_FLOATS = 32 * NP + 32;
+struct SmallFwdCfg : LsnfStackCfg<HT_, WT_> {
+    using S = LsnfStackCfg<HT_, WT_>;
+    using S::HT; using S::WT; using S::NZT;
+    static constexpr int BLOCK_FLOATS = S::FWD_BLOCK, CONST_FLOATS = S::FWD_CONST;
     using S1 = SmallStage<NZT, NZT>;                           // v  = Wa^T x + ca
     using S2 = SmallStage<WT, HT>;                             // h1 = W1'^T v1 + c1        (relu applied by the reader)
     using S3 = SmallStage<WT, WT>;                             // h2 = W2'^T relu(h1) + c2
@@ -160,25 +156,7 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_fwd_kernel(cons
             double dl = (live && h == 0) ? (double)ll : 0.0, dd = (live && h == 0) ? (double)ell : 0.0;
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) { dl += __shfl_xor(dl, o, 64); dd += __shfl_xor(dd, o, 64); }
-            if (lane == 0) {
-                const double r0 = atomicAdd(&a.stats[0], dl);
-                const double r1 = atomicAdd(&a.stats[1], dd);
-                unsigned long long inc = 1ull;
-                asm volatile("" : "+v"(inc) : "v"(r0), "v"(r1));
-                unsigned long long* ticket = reinterpret_cast<unsigned long long*>(&a.stats[2]);
-                const unsigned long long t = atomicAdd(ticket, inc);
-                if (t == (unsigned long long)gridDim.x - 1) {
-    // every other workgroup's adds were performed before its ticket.  The totals are read with atomic
-                // read-modify-writes (performed at the memory side like the adds: a plain or sc1 load could be served
-                // by this XCD's L2, which is not coherent with the other XCDs); the two reads are independent, so
-                // they cost one round trip; the re-arming atomics are fire-and-forget.
-                const double fl = atomicAdd(&a.stats[0], 0.0);
-                const double fd = atomicAdd(&a.stats[1], 0.0);
-                a.stats[4] = fl; a.stats[5] = fd; a.stats[6] = (double)a.B;
-                atomicAdd(&a.stats[0], -fl); atomicAdd(&a.stats[1], -fd);
-                atomicExch(ticket, 0ull);
-                }
-            }
+            if (lane == 0) lsnf_publish_stats(a.stats, dl, dd, a.B);
         }
     }
 }
