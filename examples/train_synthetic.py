@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Synthetic training iterations of the reference's loop (train.py:376-415) on top of the MI355X flow prior:
+K-step Langevin sampling (generator gradient by torch autograd + the fused flow step), generator Adam step,
+flow-MLE Adam step -- for the four dataset geometries of the reference's README, with synthetic images.
+
+    python examples/train_synthetic.py --dataset svhn                               # BASELINE.json configs[1]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+           examples/train_synthetic.py --dataset celeba                             # configs[3]: data parallel
+    ... --dataset celeba_hq256                                                      # configs[4]
+
+Multi-GPU: one process per GPU (RCCL); the image batch and the latents are sharded by rank, the generator is wrapped
+in stock DistributedDataParallel, the flow's parameter gradients travel as ONE flat bucket
+(`lsnf_amd.parallel.allreduce_gradients`), its weights are broadcast once.  The Langevin loop itself needs no
+communication (per-sample).  The generator is a stock DCGAN-style ConvTranspose2d stack of the dataset's output
+shape -- a stand-in: the reference's `_netG` (MIOpen convolutions) is outside the scope of the hand-written kernels.
+Prints one JSON line per run (rank 0): ms/iteration and the flow's share of it."""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import torch.nn as nn
+
+import lsnf_amd
+from lsnf_amd import langevin, parallel
+
+# dataset -> (image size, nz, ngf, f_width, Langevin steps): README.md:30-66 of the reference
+GEOMETRY = {"svhn": (32, 100, 64, 64, 20), "cifar10": (32, 128, 128, 64, 40),
+            "celeba": (64, 100, 128, 64, 20), "celeba_hq256": (256, 100, 128, 128, 20)}
+
+
+def make_generator(nz, ngf, nc, size):
+    """4x4 seed, then x2 per layer until `size`; channels halve from 8*ngf down to ngf; LeakyReLU(0.2); tanh output."""
+    layers, ch, hw = [nn.ConvTranspose2d(nz, ngf * 8, 4, 1, 0), nn.LeakyReLU(0.2)], ngf * 8, 4
+    while hw * 2 < size:
+        nxt = max(ngf, ch // 2)
+        layers += [nn.ConvTranspose2d(ch, nxt, 4, 2, 1), nn.LeakyReLU(0.2)]
+        ch, hw = nxt, hw * 2
+    layers += [nn.ConvTranspose2d(ch, nc, 4, 2, 1), nn.Tanh()]
+    return nn.Sequential(*layers)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dataset", choices=sorted(GEOMETRY), default="svhn")
+    ap.add_argument("--batch", type=int, default=100, help="images per GPU (reference: 100, train.py:46)")
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    args = ap.parse_args()
+    size, nz, ngf, f_width, K = GEOMETRY[args.dataset]
+    step_size, sigma, nc, B = 0.1, 0.3, 3, args.batch
+
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    rank, world, _ = parallel.init_from_env(dev)
+    torch.manual_seed(1); np.random.seed(1)                     # same initial weights on every rank
+    hps = types.SimpleNamespace(f_n_levels=1, f_depth=5, f_flow_permutation=2, f_width=f_width, f_flow_coupling=1)
+    netG = make_generator(nz, ngf, nc, size).to(dev)
+    netF = lsnf_amd._netF(hps, nz=nz).to(dev)
+    parallel.broadcast_parameters(netF._param_list())
+    if world > 1:
+        netG = nn.parallel.DistributedDataParallel(netG, device_ids=[local_rank])
+    optG = torch.optim.Adam(netG.parameters(), lr=3e-4, betas=(0.5, 0.999))
+    optF = torch.optim.Adam(netF.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    mse = nn.MSELoss(reduction="sum")
+    gen = torch.Generator(device=dev).manual_seed(100 + rank)   # every rank owns different rows
+    x = torch.tanh(torch.randn(B, nc, size, size, device=dev, generator=gen))
+
+    def iteration():
+        z0 = torch.randn(B, nz, 1, 1, device=dev, generator=gen)
+        gmod = netG.module if world > 1 else netG               # Langevin needs d/dz only: no gradient sync
+        zk, ggn, gfn, f = langevin.sample_langevin_post_z_with_flow(z0, x, gmod, netF, g_l_steps=K, g_l_step_size=step_size,
+                                                                    g_llhd_sigma=sigma, g_l_with_noise=True, generator=gen)
+        optG.zero_grad()
+        loss_g = mse(netG(zk), x) / B                           # train.py:391-393 (DDP averages the gradients)
+        loss_g.backward()
+        optG.step()
+        optF.zero_grad()                                        # train.py:404-415 with the one-bucket all-reduce
+        z1, logdet, _ = netF(zk.view(B, nz), objective=torch.zeros(B, device=dev))
+        loss_f = -(-0.5 * (z1 ** 2).sum(1) + float(np.log(2 * np.pi)) + logdet).mean()
+        loss_f.backward()
+        parallel.allreduce_gradients(netF.parameters(), average=True)
+        torch.nn.utils.clip_grad_norm_(netF.parameters(), 100.0)
+        optF.step()
+        return loss_g.detach(), loss_f.detach()
+
+    def wall(fn, n):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n):
+            out = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3, out
+
+    wall(iteration, args.warmup)
+    ms_iter, (lg, lf) = wall(iteration, args.iters)
+    z2d = torch.randn(B, nz, device=dev); gg = torch.randn(B, nz, device=dev); nn_ = torch.randn(B, nz, device=dev)
+    ms_flow, _ = wall(lambda: netF.langevin_step(z2d, gg, nn_, step_size), 200)
+    zk = torch.randn(B, nz, 1, 1, device=dev)
+    ms_mle, _ = wall(lambda: langevin.flow_mle_step(netF, optF, zk, f_max_norm=100.0), 20)
+    if world > 1:
+        t = torch.tensor([ms_iter], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        ms_iter = t.item()
+    if rank == 0:
+        print(json.dumps({"config": f"{args.dataset} {size}x{size} nz={nz} ngf={ngf} f_width={f_width} g_l_steps={K} "
+                                    f"B={B}/GPU x {world} GPU(s), synthetic x",
+                          "ms_per_iteration": ms_iter, "iterations_per_s": 1e3 / ms_iter, "images_per_s": world * B * 1e3 / ms_iter,
+                          "flow_langevin_step_ms": ms_flow, "flow_mle_step_ms": ms_mle,
+                          "flow_share_of_iteration": (K * ms_flow + ms_mle) / ms_iter,
+                          "loss_g": lg.item(), "loss_f": lf.item()}), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
