@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=300)   # the chip needs ~50 ms of sustained load to reach its steady clock
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
+                    "rehearse the multi-rank logic on a box with fewer GPUs than ranks)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the independent steps alternate over (2: the head of step i+1 overlaps the tail of step i)")
     args = ap.parse_args()
@@ -108,12 +110,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the flow path has no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)   # RCCL
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL
+        else:
+            dist.init_process_group(args.backend)
 
     import lsnf_amd
     weights = synth_weights(1)
