@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LSNF_ABI_VERSION 1
+#define LSNF_ABI_VERSION 2
 
 #define LSNF_OK 0
 #define LSNF_E_ARG (-1)       /* bad argument (NULL pointer, size out of range, misaligned) */
@@ -95,6 +95,10 @@ int lsnf_prepare(const float* const* params_host, int nz, int width, int depth, 
  *   ll_out    (B) or NULL: -0.5*sum_j z_out^2 + log(2*pi) + logdet_out  (train.py:317-319)
  *   z_saved   NULL, or ((n_blocks-1), B, nz): outputs of all but the last block, kept for
  *             lsnf_backward_z / lsnf_backward_params.
+ *   act_saved NULL, or lsnf_act_saved_floats(nz,width,depth,B) floats (16-byte aligned): opaque stash of
+ *             what autograd would keep besides the block outputs (the coupling's sigmoid and the two
+ *             relu masks, model.py:307-308,415), indexed by absolute block.  Handing it to
+ *             lsnf_backward_z / lsnf_langevin_step removes their recomputation of the coupling MLP.
  *   stats     NULL, or 8 doubles (device, 8-byte aligned) that the caller zero-initialises ONCE:
  *             after the launch stats[4] = sum_b ll_b (train.py:320), stats[5] = sum_b logdet_b,
  *             stats[6] = B.  Summed inside the kernel (fp64 atomics, one pair per workgroup; the last
@@ -104,7 +108,10 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling,
                  int first_block, int n_blocks, int B,
                  const float* z_in, const float* objective,
                  float* z_out, float* logdet_out, float* ll_out, float* z_saved,
-                 double* stats, void* stream);
+                 float* act_saved, double* stats, void* stream);
+
+/* floats of lsnf_forward's optional activation stash for a batch of B rows (0 on bad geometry) */
+size_t lsnf_act_saved_floats(int nz, int width, int depth, int B);
 
 /* ---- reverse: replaces `_netF.forward(z, objective, reverse=True)` (model.py:484-498,
  * block inverse model.py:424-456).  Functional: inputs are not modified (the reference
@@ -117,12 +124,13 @@ int lsnf_reverse(const float* plan, int nz, int width, int depth, int coupling, 
 /* ---- backward w.r.t. z: replaces autograd of train.py:316-323 ---------------------------
  * Given upstream gradients g_z1 = dL/dz_out (B,nz) (NULL = 0), g_logdet = dL/dlogdet_out
  * (B) (NULL = 0) computes g_z_in = dL/dz_in (B,nz).  z_out / z_saved are what lsnf_forward
- * wrote for the same inputs (full stack: first_block = 0, n_blocks = depth).
+ * wrote for the same inputs (full stack: first_block = 0, n_blocks = depth); act_saved is
+ * NULL (the coupling MLP is recomputed from z_saved) or the stash that forward filled.
  * If ll_mode != 0 the upstream gradient is that of L = ll_scale * sum_b ll_b, i.e.
  * g_z1 = -ll_scale*z_out, g_logdet = ll_scale, and the two pointers are ignored
  * (train.py:320 uses L = -sum ll -> ll_scale = -1). */
 int lsnf_backward_z(const float* plan, int nz, int width, int depth, int coupling, int B,
-                    const float* z_out, const float* z_saved,
+                    const float* z_out, const float* z_saved, const float* act_saved,
                     const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
                     float* g_z_in, void* stream);
 
@@ -130,12 +138,13 @@ int lsnf_backward_z(const float* plan, int nz, int width, int depth, int couplin
  * One launch computes g_f = d(-sum ll)/dz (as lsnf_backward_z with ll_mode=1, ll_scale=-1) and applies
  *     z_new = z_cur - 0.5*s^2 * (grad_g + g_f) + s * noise          (train.py:324,326)
  * plus the per-sample gradient norms of train.py:328-329 (the caller takes their mean).
- *   z_cur  (B,nz) current latents (the z that lsnf_forward was run on); z_out / z_saved from that forward
+ *   z_cur  (B,nz) current latents (the z that lsnf_forward was run on); z_out / z_saved / act_saved
+ *          (act_saved may be NULL) from that forward
  *   grad_g (B,nz) or NULL (= 0): the generator's gradient z_grad_g (train.py:314)
  *   noise  (B,nz) or NULL (= no noise, as the test-time sampler train.py:624-625): N(0,1) draws
  *   z_new  (B,nz), may alias z_cur (in-place update);  gf_norm, gg_norm: (B) or NULL. */
 int lsnf_langevin_step(const float* plan, int nz, int width, int depth, int coupling, int B,
-                       const float* z_cur, const float* z_out, const float* z_saved,
+                       const float* z_cur, const float* z_out, const float* z_saved, const float* act_saved,
                        const float* grad_g, const float* noise, float step_size,
                        float* z_new, float* gf_norm, float* gg_norm, void* stream);
 

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LSNF_LIB_PATH") or os.path.join(_HERE, "liblsnf_flow.so")
 
 LSNF_PARAMS_PER_BLOCK = 12
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # name -> (restype, argtypes); mirrors include/lsnf_flow.h one to one
 _SIGNATURES = {
@@ -25,13 +25,14 @@ _SIGNATURES = {
     "lsnf_prepare_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
     "lsnf_prepare": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "lsnf_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lsnf_act_saved_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "lsnf_reverse": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int,
                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lsnf_backward_z": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
     "lsnf_langevin_step": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
     "lsnf_backward_params_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "lsnf_backward_params": (c_int, [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),

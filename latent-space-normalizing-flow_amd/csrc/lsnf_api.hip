@@ -19,21 +19,23 @@ hipError_t lsnf_launch_prepare(const LsnfGeo& g, const float* const* params_host
 size_t lsnf_prep_scratch_bytes(int nz, int depth);
 hipError_t lsnf_launch_forward(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                const float* z_in, const float* objective, float* z_out, float* logdet_out,
-                               float* ll_out, float* z_saved, double* stats, int vec4, hipStream_t stream);
+                               float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
+                               hipStream_t stream);
 hipError_t lsnf_launch_small_forward(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                      const float* z_in, const float* objective, float* z_out, float* logdet_out,
-                                     float* ll_out, float* z_saved, double* stats, int vec4, hipStream_t stream);
+                                     float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
+                                     hipStream_t stream);
 hipError_t lsnf_launch_reverse(const LsnfGeo& g, const float* plan, int B, const float* z_in, const float* objective,
                                float* z_out, float* objective_out, int vec4, hipStream_t stream);
 hipError_t lsnf_launch_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
                                   const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
                                   float* g_z_in, float* dump, float* gl_total, int vec4, hipStream_t stream,
-                                  const LsnfLangevinArgs* lv = nullptr);
+                                  const LsnfLangevinArgs* lv = nullptr, const float* act_saved = nullptr);
 hipError_t lsnf_launch_small_reverse(const LsnfGeo& g, const float* plan, int B, const float* z_in, const float* objective,
                                      float* z_out, float* objective_out, int vec4, hipStream_t stream);
 hipError_t lsnf_launch_small_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
                                         const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale, float* g_z_in,
-                                        int vec4, hipStream_t stream, const LsnfLangevinArgs* lv);
+                                        int vec4, hipStream_t stream, const LsnfLangevinArgs* lv, const float* act_saved);
 hipError_t lsnf_launch_backward_params(const LsnfGeo& g, const float* plan, const float* const* params_host,
                                        float* const* grads_host, int B, const float* z_in, const float* z_out,
                                        const float* z_saved, const float* g_z1, const float* g_logdet, int ll_mode,
@@ -131,7 +133,7 @@ int lsnf_prepare(const float* const* params_host, int nz, int width, int depth, 
 
 int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, int first_block, int n_blocks, int B,
                  const float* z_in, const float* objective, float* z_out, float* logdet_out, float* ll_out,
-                 float* z_saved, double* stats, void* stream) {
+                 float* z_saved, float* act_saved, double* stats, void* stream) {
     LsnfGeo g;
     if (int rc = geo_or_fail(&g, nz, width, depth, coupling)) return rc;
     if (B < 0 || B > (1 << 28)) return fail(LSNF_E_ARG, "lsnf_forward: B=%d out of range", B);
@@ -148,16 +150,23 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
         return fail(LSNF_E_ARG, "lsnf_forward: tensors must be 4-byte aligned");
     if (B == 0) return LSNF_OK;
     const int vec4 = row_vector_width(g, {z_in, z_out, z_saved});
+    if (act_saved && !aligned16(act_saved)) return fail(LSNF_E_ARG, "lsnf_forward: act_saved must be 16-byte aligned");
     if (stats && (reinterpret_cast<uintptr_t>(stats) & 7u)) return fail(LSNF_E_ARG, "lsnf_forward: stats must be 8-byte aligned");
     // batch-size dispatch: latency kernel (32 rows per workgroup, stages split over the 4 waves) below the
     // crossover, throughput kernel (128 rows per workgroup, weights shared through LDS) above it
     hipError_t e = (B <= small_batch_max())
         ? lsnf_launch_small_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
-                                    z_saved, stats, vec4, (hipStream_t)stream)
+                                    z_saved, act_saved, stats, vec4, (hipStream_t)stream)
         : lsnf_launch_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
-                              z_saved, stats, vec4, (hipStream_t)stream);
+                              z_saved, act_saved, stats, vec4, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "lsnf_forward launch");
     return LSNF_OK;
+}
+
+size_t lsnf_act_saved_floats(int nz, int width, int depth, int B) {
+    LsnfGeo g;
+    if (lsnf_geo_init(&g, nz, width, depth, 1) || B < 0) return 0;   // independent of the coupling type
+    return (size_t)depth * lsnf_act_layout(B, g.HT, g.WT).per_block;
 }
 
 int lsnf_reverse(const float* plan, int nz, int width, int depth, int coupling, int B, const float* z_in,
@@ -180,8 +189,8 @@ int lsnf_reverse(const float* plan, int nz, int width, int depth, int coupling, 
 }
 
 int lsnf_backward_z(const float* plan, int nz, int width, int depth, int coupling, int B, const float* z_out,
-                    const float* z_saved, const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
-                    float* g_z_in, void* stream) {
+                    const float* z_saved, const float* act_saved, const float* g_z1, const float* g_logdet, int ll_mode,
+                    float ll_scale, float* g_z_in, void* stream) {
     LsnfGeo g;
     if (int rc = geo_or_fail(&g, nz, width, depth, coupling)) return rc;
     if (B < 0 || B > (1 << 28)) return fail(LSNF_E_ARG, "lsnf_backward_z: B=%d out of range", B);
@@ -192,18 +201,19 @@ int lsnf_backward_z(const float* plan, int nz, int width, int depth, int couplin
         return fail(LSNF_E_ARG, "lsnf_backward_z: tensors must be 4-byte aligned");
     if (B == 0) return LSNF_OK;
     const int vec4 = row_vector_width(g, {z_out, g_z_in, z_saved, g_z1});
+    if (act_saved && !aligned16(act_saved)) return fail(LSNF_E_ARG, "lsnf_backward_z: act_saved must be 16-byte aligned");
     hipError_t e = (B <= small_batch_max())
         ? lsnf_launch_small_backward_z(g, plan, B, z_out, z_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, vec4,
-                                       (hipStream_t)stream, nullptr)
+                                       (hipStream_t)stream, nullptr, act_saved)
         : lsnf_launch_backward_z(g, plan, B, z_out, z_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, nullptr,
-                                 nullptr, vec4, (hipStream_t)stream);
+                                 nullptr, vec4, (hipStream_t)stream, nullptr, act_saved);
     if (e != hipSuccess) return hip_fail(e, "lsnf_backward_z launch");
     return LSNF_OK;
 }
 
 int lsnf_langevin_step(const float* plan, int nz, int width, int depth, int coupling, int B, const float* z_cur,
-                       const float* z_out, const float* z_saved, const float* grad_g, const float* noise, float step_size,
-                       float* z_new, float* gf_norm, float* gg_norm, void* stream) {
+                       const float* z_out, const float* z_saved, const float* act_saved, const float* grad_g,
+                       const float* noise, float step_size, float* z_new, float* gf_norm, float* gg_norm, void* stream) {
     LsnfGeo g;
     if (int rc = geo_or_fail(&g, nz, width, depth, coupling)) return rc;
     if (B < 0 || B > (1 << 28)) return fail(LSNF_E_ARG, "lsnf_langevin_step: B=%d out of range", B);
@@ -214,12 +224,13 @@ int lsnf_langevin_step(const float* plan, int nz, int width, int depth, int coup
         !aligned4(gf_norm) || !aligned4(gg_norm))
         return fail(LSNF_E_ARG, "lsnf_langevin_step: tensors must be 4-byte aligned");
     const int vec4 = row_vector_width(g, {z_out, z_saved, z_cur, grad_g, noise, z_new});
+    if (act_saved && !aligned16(act_saved)) return fail(LSNF_E_ARG, "lsnf_langevin_step: act_saved must be 16-byte aligned");
     LsnfLangevinArgs lv = {z_cur, grad_g, noise, z_new, gf_norm, gg_norm, step_size};
     hipError_t e = (B <= small_batch_max())
         ? lsnf_launch_small_backward_z(g, plan, B, z_out, z_saved, nullptr, nullptr, /*ll_mode=*/1, /*ll_scale=*/-1.0f,
-                                       nullptr, vec4, (hipStream_t)stream, &lv)
+                                       nullptr, vec4, (hipStream_t)stream, &lv, act_saved)
         : lsnf_launch_backward_z(g, plan, B, z_out, z_saved, nullptr, nullptr, /*ll_mode=*/1, /*ll_scale=*/-1.0f,
-                                 nullptr, nullptr, nullptr, vec4, (hipStream_t)stream, &lv);
+                                 nullptr, nullptr, nullptr, vec4, (hipStream_t)stream, &lv, act_saved);
     if (e != hipSuccess) return hip_fail(e, "lsnf_langevin_step launch");
     return LSNF_OK;
 }

@@ -25,6 +25,7 @@ struct BwdArgs {
     float* g_z_in;          // may be NULL when only parameter gradients are wanted
     float* dump;            // DUMP variant: per-block intermediates for the parameter gradients (lsnf_layout.h)
     float* gl_total;        // DUMP variant: += sum_b dL/dlogdet_b
+    const float* act_saved; // SAVED variant: activation stash of the forward (sigma, relu masks): no MLP recompute
     // fused Langevin update (train.py:324-329): z_new = z_cur - 0.5 s^2 (grad_g + g_z_in) + s * noise
     const float* z_cur; const float* grad_g; const float* noise; float* z_new; float* gf_norm; float* gg_norm;
     float step;
@@ -58,8 +59,12 @@ __device__ __forceinline__ void store_plain(const f32x16* x, float* __restrict__
 // NW waves per workgroup (4: two workgroups per CU, 8: one; see lsnf_fwd.hip)
 // Wide MLPs (WT = 4, e.g. f_width = 128) need ~300 live VGPRs in the backward: give them the whole register file
 // (one wave per SIMD) instead of spilling 80-110 registers to scratch at two waves per SIMD.
-template <class C, bool DUMP, int NW>
-__global__ __launch_bounds__(64 * NW, (C::WT >= 4 ? 1 : 2)) void lsnf_bwd_z_kernel(const BwdArgs a) {
+// SAVED: sigma and the relu masks come from the forward's activation stash (lsnf_forward act_saved) instead of being
+// recomputed: the three MLP GEMMs (1/3 of this kernel's MFMA work) disappear.  DUMP needs the h1/h2 VALUES, so it
+// always recomputes (DUMP implies !SAVED).
+template <class C, bool DUMP, int NW, bool SAVED>
+__global__ __launch_bounds__(64 * NW, ((C::WT >= 4 && !SAVED) ? 1 : 2)) void lsnf_bwd_z_kernel(const BwdArgs a) {
+    static_assert(!(DUMP && SAVED), "the parameter-gradient dump needs the recomputed activations");
     constexpr int HT = C::HT, WT = C::WT, NZT = C::NZT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* cst = smem;                                   // depth * CONST_USED
@@ -71,7 +76,8 @@ __global__ __launch_bounds__(64 * NW, (C::WT >= 4 ? 1 : 2)) void lsnf_bwd_z_kern
     pipe.lane = tid & 63;
     const int lane = pipe.lane, m = lane & 31, h = lane >> 5;
 
-    pipe.template prime<HT>(a.fwd_panels + (size_t)(a.depth - 1) * C::FWD_BLOCK + C::OFF_S2);
+    if constexpr (SAVED) pipe.template prime<2 * HT>(a.bwd_panels + (size_t)(a.depth - 1) * C::BWD_BLOCK + C::OFF_B4);
+    else pipe.template prime<HT>(a.fwd_panels + (size_t)(a.depth - 1) * C::FWD_BLOCK + C::OFF_S2);
     for (int i = tid; i < a.depth * C::CONST_USED; i += 64 * NW) {
         const int blk = i / C::CONST_USED, r = i % C::CONST_USED;
         cst[i] = a.fwd_consts[blk * C::FWD_CONST + 32 * C::P1 + r];
@@ -106,17 +112,40 @@ __global__ __launch_bounds__(64 * NW, (C::WT >= 4 ? 1 : 2)) void lsnf_bwd_z_kern
         if (lane == 0) atomicAdd(a.gl_total, t);
     }
     const LsnfDumpLayout dl = lsnf_dump_layout(a.B, a.nz, a.width);
+    const LsnfActLayout al = lsnf_act_layout(a.B, HT, WT);
+    size_t wtile = (size_t)blockIdx.x * NW + pipe.wave;              // this wave's 32-sample tile (clamped: waves past
+    if (wtile * 32 >= (size_t)a.B) wtile = (size_t)(a.B - 1) / 32;   // the batch read a valid tile and store nothing)
 
     for (int blk = a.depth - 1; blk >= 0; --blk) {
         const float* cb = cst + blk * C::CONST_USED;
         const float* gf = a.fwd_panels + (size_t)blk * C::FWD_BLOCK;
         const float* gb = a.bwd_panels + (size_t)blk * C::BWD_BLOCK;
-        const float* gnext = blk > 0 ? a.fwd_panels + (size_t)(blk - 1) * C::FWD_BLOCK + C::OFF_S2 : nullptr;
+        const float* gnext = blk == 0 ? nullptr
+                           : (SAVED ? a.bwd_panels + (size_t)(blk - 1) * C::BWD_BLOCK + C::OFF_B4
+                                    : a.fwd_panels + (size_t)(blk - 1) * C::FWD_BLOCK + C::OFF_S2);
         const float* ysrc = (blk == a.depth - 1) ? a.z_out : a.z_saved + (size_t)blk * a.B * a.nz;
 
         f32x16 y[NZT];     // block output [v1 | y2]
         lsnf_load_rows<HT>(y, ysrc, row, a.nz, a.half, h, vec4);
-
+        unsigned m1[WT], m2[WT];
+        f32x16 tp[2 * HT];
+        float* dmp = nullptr;
+        if constexpr (SAVED) {
+            const float* act = a.act_saved + (size_t)blk * al.per_block + wtile * al.per_tile;
+#pragma unroll
+            for (int t = 0; t < WT; ++t) { m1[t] = *lsnf_act_mask_ptr(act, al.mask_off, t, lane); m2[t] = *lsnf_act_mask_ptr(act, al.mask_off, WT + t, lane); }
+            // ---- coupling backward with the stashed sigma: tp[0..HT) <- g_t (= g_v2), tp[HT..2HT) <- g_p ----
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+                const f32x16 sg = lsnf_act_load_sigma(act, t, lane);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float gy2 = gx[HT + t][r];
+                    tp[t][r] = gy2 * sg[r];
+                    tp[HT + t][r] = (1.0f - sg[r]) * (gy2 * y[HT + t][r] + gl);
+                }
+            }
+        } else {
         // ---- recompute the MLP (forward panels S2..S4) ----
         f32x16 h1[WT];
         lsnf_static_for<WT>([&](auto nt) {
@@ -134,10 +163,8 @@ __global__ __launch_bounds__(64 * NW, (C::WT >= 4 ? 1 : 2)) void lsnf_bwd_z_kern
             lsnf_panel_mma<WT>(h2[nt], h1, lb, lane);
             h2[nt] = lsnf_relu16(h2[nt]);
         });
-        unsigned m1[WT], m2[WT];
 #pragma unroll
         for (int t = 0; t < WT; ++t) m1[t] = lsnf_posmask16(h1[t]);
-        f32x16 tp[2 * HT];
         lsnf_static_for<2 * HT>([&](auto nt) {
             const float* lb;
             if constexpr (nt + 1 < 2 * HT) lb = pipe.template acquire<WT>(gf + C::OFF_S4 + (nt + 1) * WT * LSNF_FRAG_FLOATS);
@@ -147,7 +174,6 @@ __global__ __launch_bounds__(64 * NW, (C::WT >= 4 ? 1 : 2)) void lsnf_bwd_z_kern
         });
 #pragma unroll
         for (int t = 0; t < WT; ++t) m2[t] = lsnf_posmask16(h2[t]);
-        float* dmp = nullptr;
         if constexpr (DUMP) {
             dmp = a.dump + (size_t)blk * dl.per_block;
             if (live) {
@@ -167,6 +193,7 @@ __global__ __launch_bounds__(64 * NW, (C::WT >= 4 ? 1 : 2)) void lsnf_bwd_z_kern
                 tp[t][r] = gy2 * sig;
                 tp[HT + t][r] = (1.0f - sig) * (gy2 * y[HT + t][r] + gl);
             }
+        }   // !SAVED
         if constexpr (DUMP) {
             if (live) {
                 store_plain<HT>(tp, dmp + dl.off_gt, sample, a.half, h);
@@ -209,7 +236,7 @@ __global__ __launch_bounds__(64 * NW, (C::WT >= 4 ? 1 : 2)) void lsnf_bwd_z_kern
         lsnf_static_for<NZT>([&](auto nt) {
             const float* lb;
             if constexpr (nt + 1 < NZT) lb = pipe.template acquire<NZT>(gb + C::OFF_B1 + (nt + 1) * NZT * LSNF_FRAG_FLOATS);
-            else lb = pipe.template acquire<HT>(gnext);
+            else lb = pipe.template acquire<(SAVED ? 2 * HT : HT)>(gnext);
             gx[nt] = lsnf_zero16();
             lsnf_panel_mma<NZT>(gx[nt], gv, lb, lane);
         });
@@ -250,10 +277,10 @@ __global__ __launch_bounds__(64 * NW, (C::WT >= 4 ? 1 : 2)) void lsnf_bwd_z_kern
     }
 }
 
-template <class C, bool DUMP, int NW>
+template <class C, bool DUMP, int NW, bool SAVED>
 hipError_t launch_bwd_w(const BwdArgs& a, hipStream_t stream) {
     const size_t lds = ((size_t)a.depth * C::CONST_USED + 2 * (size_t)C::SLOT) * sizeof(float);
-    auto kern = lsnf_bwd_z_kernel<C, DUMP, NW>;
+    auto kern = lsnf_bwd_z_kernel<C, DUMP, NW, SAVED>;
     static unsigned long long lds_ok = 0;
     if (hipError_t e = lsnf_allow_big_lds((const void*)kern, &lds_ok); e != hipSuccess) return e;
     const unsigned grid = (unsigned)((a.B + 32 * NW - 1) / (32 * NW));
@@ -263,7 +290,8 @@ hipError_t launch_bwd_w(const BwdArgs& a, hipStream_t stream) {
 template <class C, bool DUMP>
 hipError_t launch_bwd(const BwdArgs& a, hipStream_t stream) {
     // measured at B = 65536: 248 us with 4-wave workgroups, 263 us with 8 (more stages -> more, costlier 8-wave barriers)
-    return launch_bwd_w<C, DUMP, 4>(a, stream);
+    if constexpr (!DUMP) { if (a.act_saved) return launch_bwd_w<C, false, 4, true>(a, stream); }
+    return launch_bwd_w<C, DUMP, 4, false>(a, stream);
 }
 }  // namespace
 
@@ -272,8 +300,9 @@ hipError_t launch_bwd(const BwdArgs& a, hipStream_t stream) {
 hipError_t lsnf_launch_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
                                   const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
                                   float* g_z_in, float* dump, float* gl_total, int vec4, hipStream_t stream,
-                                  const LsnfLangevinArgs* lv) {
+                                  const LsnfLangevinArgs* lv, const float* act_saved) {
     BwdArgs a;
+    a.act_saved = dump ? nullptr : act_saved;
     a.dump = dump; a.gl_total = gl_total; a.width = g.width;
     a.z_cur = nullptr; a.grad_g = nullptr; a.noise = nullptr; a.z_new = nullptr; a.gf_norm = nullptr; a.gg_norm = nullptr; a.step = 0.f;
     if (lv) { a.z_cur = lv->z_cur; a.grad_g = lv->grad_g; a.noise = lv->noise; a.z_new = lv->z_new; a.gf_norm = lv->gf_norm;

@@ -372,6 +372,26 @@ __device__ __forceinline__ void lsnf_gemm_stage(Pipe& pipe, const float* gsrc, c
 // k-tiles x tiles of the FIRST panel pair of a stage with NT tiles of KT k-tiles
 __device__ __forceinline__ constexpr int lsnf_first_ktc(int NT, int KT) { return KT * (NT >= 2 ? 2 : 1); }
 
+// activation stash helpers (lsnf_layout.h, LsnfActLayout): sigma tile / relu-mask word of one 32-sample tile
+__device__ __forceinline__ void lsnf_act_store_sigma(float* tile_base, int t, const f32x16& sg, int lane) {
+    f32x4* p = reinterpret_cast<f32x4*>(tile_base + (size_t)t * 1024) + lane;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { f32x4 v = {sg[4 * g], sg[4 * g + 1], sg[4 * g + 2], sg[4 * g + 3]}; p[g * 64] = v; }
+}
+__device__ __forceinline__ f32x16 lsnf_act_load_sigma(const float* tile_base, int t, int lane) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(tile_base + (size_t)t * 1024) + lane;
+    f32x16 a;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { const f32x4 v = p[g * 64]; a[4 * g] = v[0]; a[4 * g + 1] = v[1]; a[4 * g + 2] = v[2]; a[4 * g + 3] = v[3]; }
+    return a;
+}
+__device__ __forceinline__ unsigned* lsnf_act_mask_ptr(float* tile_base, size_t mask_off, int idx, int lane) {
+    return reinterpret_cast<unsigned*>(tile_base + mask_off) + idx * 64 + lane;
+}
+__device__ __forceinline__ const unsigned* lsnf_act_mask_ptr(const float* tile_base, size_t mask_off, int idx, int lane) {
+    return reinterpret_cast<const unsigned*>(tile_base + mask_off) + idx * 64 + lane;
+}
+
 // bit r of the result = (a[r] > 0): relu mask of one tile, for the backward pass
 __device__ __forceinline__ unsigned lsnf_posmask16(const f32x16& a) {
     unsigned m = 0;

@@ -32,6 +32,7 @@ struct FwdArgs {
     float* logdet_out;
     float* ll_out;
     float* z_saved;
+    float* act_saved;                  // NULL or the activation stash (lsnf_layout.h: LsnfActLayout) read by the SAVED backward
     int B, nz, half, n_blocks, vec4;
     double* stats;                     // NULL or 8 doubles: see lsnf_forward (in-kernel sum of ll / logdet over the batch)
     unsigned long long* stamps;        // LSNF_STAMPS diagnostic build only: [grid][4 waves][64] shader-clock stamps
@@ -93,7 +94,11 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void lsnf_fwd_kernel(const FwdAr
 #endif
 
     LSNF_STAMP(1);
+    const LsnfActLayout al = lsnf_act_layout(a.B, HT, WT);
+    const size_t wtile = (size_t)blockIdx.x * FWD_WAVES + wave;          // this wave's 32-sample tile
     for (int blk = 0; blk < a.n_blocks; ++blk) {
+        float* act = (a.act_saved && wtile * 32 < (size_t)a.B)      // waves past the batch own no stash tile
+                         ? a.act_saved + (size_t)blk * al.per_block + wtile * al.per_tile : nullptr;
         const float* cb = cst + blk * C::CONST_FLOATS;
         const float* gblk = a.panels + (size_t)blk * C::BLOCK_FLOATS;
         const bool more = blk + 1 < a.n_blocks;
@@ -121,12 +126,20 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void lsnf_fwd_kernel(const FwdAr
         f32x16 h1[WT];
         lsnf_gemm_stage<C::P2, C::KT2, lsnf_first_ktc(C::P3, C::KT3)>(
             pipe, gblk + C::OFF_S2, gblk + C::OFF_S3, h1, v, [&](int t) { return lsnf_bias_init(cb + 32 * (C::P1 + t), h); }, relu);
+        if (act) {
+#pragma unroll
+            for (int t = 0; t < WT; ++t) *lsnf_act_mask_ptr(act, al.mask_off, t, lane) = lsnf_posmask16(h1[t]);
+        }
         LSNF_STAMP(2 + 6 * blk + 1);
         // ---- S3: h2 = relu(actnorm(h1 @ W2))  (model.py:326-328,308) ----
         f32x16 h2[WT];
         lsnf_gemm_stage<C::P3, C::KT3, lsnf_first_ktc(C::P4, C::KT4)>(
             pipe, gblk + C::OFF_S3, gblk + C::OFF_S4, h2, h1,
             [&](int t) { return lsnf_bias_init(cb + 32 * (C::P1 + C::P2 + t), h); }, relu);
+        if (act) {
+#pragma unroll
+            for (int t = 0; t < WT; ++t) *lsnf_act_mask_ptr(act, al.mask_off, WT + t, lane) = lsnf_posmask16(h2[t]);
+        }
         LSNF_STAMP(2 + 6 * blk + 2);
         // ---- S4: shift t / pre-sigmoid p = fc_zeros(h2), de-interleaved (model.py:347-349,411-413) ----
         f32x16 tp[2 * HT];
@@ -139,13 +152,16 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void lsnf_fwd_kernel(const FwdAr
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
             x[t] = v[t];
+            f32x16 sg;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float sig, l2;
                 lsnf_sigmoid_log2(tp[HT + t][r], sig, l2);
                 x[HT + t][r] = (v[HT + t][r] + tp[t][r]) * sig;
+                sg[r] = sig;
                 lsum += l2;                                   // -log2(scale); one multiply by -ln2 per sample below
             }
+            if (act) lsnf_act_store_sigma(act, t, sg, lane);
         }
         ell = ell + -0.6931471805599453f * lsnf_pair_sum(lsum);
         LSNF_STAMP(2 + 6 * blk + 4);
@@ -225,9 +241,11 @@ extern "C" unsigned long long* lsnf_debug_stamps(void) { return g_lsnf_stamps; }
 // host-side dispatcher (called from lsnf_api.hip)
 hipError_t lsnf_launch_forward(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                const float* z_in, const float* objective, float* z_out, float* logdet_out,
-                               float* ll_out, float* z_saved, double* stats, int vec4, hipStream_t stream) {
+                               float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
+                               hipStream_t stream) {
     FwdArgs a;
     a.stats = stats;
+    a.act_saved = act_saved ? act_saved + (size_t)first_block * lsnf_act_layout(B, g.HT, g.WT).per_block : nullptr;
     a.consts = plan + g.off_fwd_const + (size_t)first_block * g.fwd_const_floats;
     a.panels = plan + g.off_fwd_panels + (size_t)first_block * g.fwd_block_floats;
     a.z_in = z_in; a.objective = objective; a.z_out = z_out; a.logdet_out = logdet_out; a.ll_out = ll_out;

@@ -142,3 +142,19 @@ static inline LsnfFoldLayout lsnf_fold_layout(int nz, int width) {
 static inline size_t lsnf_params_workspace_floats(int nz, int width, int depth, int B) {
     return 4 + (size_t)depth * lsnf_fold_layout(nz, width).per_block + (size_t)depth * lsnf_dump_layout(B, nz, width).per_block;
 }
+
+// ---- optional activation stash of the forward (act_saved), read by the backward instead of recomputing the MLP ----
+// Opaque, register-order layout, per block and per 32-sample tile `wt` (nwt = ceil(B/32) tiles):
+//   floats [0, HT*1024)          : sigma tiles, each [g(4)][lane(64)][4]  (sigma of feature tile t, accumulator layout)
+//   words  [HT*1024, +2*WT*64)   : relu masks, uint32 per lane: tiles 0..WT-1 of h1, then 0..WT-1 of h2 (bit r = h[r] > 0)
+struct LsnfActLayout { size_t per_tile, per_block, mask_off; };
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline LsnfActLayout lsnf_act_layout(int B, int HT, int WT) {
+    LsnfActLayout a;
+    a.mask_off = (size_t)HT * 1024;
+    a.per_tile = a.mask_off + (size_t)2 * WT * 64;
+    a.per_block = a.per_tile * (size_t)((B + 31) / 32);
+    return a;
+}

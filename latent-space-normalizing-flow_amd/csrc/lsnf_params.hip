@@ -24,7 +24,7 @@ enum { P_AB = 0, P_ALOGS, P_W, P_W1, P_B1, P_LOGS1, P_W2, P_B2, P_LOGS2, P_W3, P
 hipError_t lsnf_launch_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
                                   const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
                                   float* g_z_in, float* dump, float* gl_total, int vec4, hipStream_t stream,
-                                  const LsnfLangevinArgs* lv = nullptr);
+                                  const LsnfLangevinArgs* lv = nullptr, const float* act_saved = nullptr);
 
 namespace {
 

@@ -9,6 +9,7 @@
 // needs.  Weights are not shared between waves any more, so they skip LDS: each wave loads the fragments of
 // ITS panel slice straight from L2 into VGPRs (lane-linear 16 B per lane), one stage ahead of their use.
 #pragma once
+#include <type_traits>
 #include "lsnf_device.h"
 
 #define LSNF_SMALL_SAMPLES 32
@@ -95,7 +96,9 @@ struct SmallStage {
         f32x16 acc = (ks == 0) ? init(nt) : lsnf_zero16();
 #pragma unroll
         for (int k = 0; k < KTL; ++k) {
-            const f32x16 x = in(ks * KTL + k);
+            f32x16 x;   // in(kt) or in(kt, k): k is the compile-time index within this wave's K slice
+            if constexpr (std::is_invocable_v<InFn, int, int>) x = in(ks * KTL + k, k);
+            else x = in(ks * KTL + k);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 w = fr.w[k * 4 + g];

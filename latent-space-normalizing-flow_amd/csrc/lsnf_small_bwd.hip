@@ -8,6 +8,8 @@
 //   CB       : s = sigmoid(p); g_t = g_v2 = g_y2*s ; g_p = (1-s)(g_y2*y2 + g_l)
 //   B4       : g_h2 = [W3s W3p][g_t;g_p]        B3 : g_h1 = W2'(g_h2 * [h2>0])
 //   B2       : g_v1 = g_v1 + W1'(g_h1 * [h1>0]) B1 : g_x  = Wa [g_v1; g_v2]
+// SAVED variant (the forward filled act_saved): R2..R4 disappear, sigma and the relu masks come from the stash,
+// and CB is folded into B4's operand fetch -- 4 stages per block instead of 8.
 #include "lsnf_small.h"
 
 namespace {
@@ -42,16 +44,16 @@ struct SmallBwdCfg : LsnfStackCfg<HT_, WT_> {
 
 struct SmallBwdArgs {
     const float* fwd_consts; const float* fwd_panels; const float* bwd_panels;
-    const float* z_out; const float* z_saved; const float* g_z1; const float* g_logdet;
+    const float* z_out; const float* z_saved; const float* act_saved; const float* g_z1; const float* g_logdet;
     float* g_z_in;
     const float* z_cur; const float* grad_g; const float* noise; float* z_new; float* gf_norm; float* gg_norm;
     float step, ll_scale;
     int ll_mode, B, nz, half, depth, vec4;
 };
 
-template <class C>
+template <class C, bool SAVED>
 __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(const SmallBwdArgs a) {
-    constexpr int HT = C::HT, NZT = C::NZT;
+    constexpr int HT = C::HT, NZT = C::NZT, WT = C::WT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tiles = smem;
     float* aux = smem + (size_t)C::T_END * LSNF_TILE_FLOATS;
@@ -63,7 +65,25 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(cons
     auto T = [&](int t) { return tiles + (size_t)t * LSNF_TILE_FLOATS; };
 
     const int last = a.depth - 1;
-    auto f2 = C::R2::fetch(a.fwd_panels + (size_t)last * C::FWD_BLOCK + C::OFF_S2, wave, lane);
+    // first stage's weights in flight: R2 of the last block, or (SAVED) its B4
+    auto f2 = C::R2::fetch(a.fwd_panels + (size_t)last * C::FWD_BLOCK + (SAVED ? 0 : C::OFF_S2), SAVED ? 4 : wave, lane);
+    auto fb4 = C::B4::fetch(a.bwd_panels + (size_t)last * C::BWD_BLOCK + C::OFF_B4, SAVED ? wave : 4, lane);
+    // SAVED: this wave's slice of the stash, one block ahead: sigma tiles, h2 masks of its B3 slice, h1 masks
+    const LsnfActLayout al = lsnf_act_layout(a.B, HT, WT);
+    constexpr int K3 = C::B3::KTL;
+    const int ks3 = (wave < C::B3::UNITS) ? wave % C::B3::KS : 0;
+    f32x16 sg[HT];
+    unsigned mk1[WT], mk2[K3];
+    auto fetch_act = [&](int blk) {
+        const float* act = a.act_saved + (size_t)blk * al.per_block + (size_t)blockIdx.x * al.per_tile;
+#pragma unroll
+        for (int j = 0; j < HT; ++j) sg[j] = lsnf_act_load_sigma(act, j, lane);
+#pragma unroll
+        for (int k = 0; k < WT; ++k) mk1[k] = *lsnf_act_mask_ptr(act, al.mask_off, k, lane);
+#pragma unroll
+        for (int k = 0; k < K3; ++k) mk2[k] = *lsnf_act_mask_ptr(act, al.mask_off, WT + ks3 * K3 + k, lane);
+    };
+    if constexpr (SAVED) fetch_act(last);
     for (int i = tid; i < a.depth * C::CONST_USED; i += LSNF_WG_THREADS) {
         const int blk = i / C::CONST_USED, r = i % C::CONST_USED;
         cst[i] = a.fwd_consts[blk * C::FWD_CONST + 32 * C::P1 + r];
@@ -98,6 +118,7 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(cons
         float* GTP = T(C::T_GTP); float* GH2 = T(C::T_GH2); float* GH1 = T(C::T_GH1); float* GV = T(C::T_GV);
         auto tile = [&](const float* base, int t) { return small_load_tile(base + (size_t)t * LSNF_TILE_FLOATS, lane); };
 
+        if constexpr (!SAVED) {
         // ---- R2: h1 = W1'^T v1 + c1 ----
         auto f3 = C::R3::fetch(gf + C::OFF_S3, wave, lane);
         C::R2::run(f2, H1, wave, lane, [&](int kt) { return tile(Y, kt); }, [&](int nt) { return lsnf_bias_init(cb + 32 * nt, h); });
@@ -109,7 +130,7 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(cons
                    [&](int nt) { return lsnf_bias_init(cb + 32 * (C::P2 + nt), h); });
         __syncthreads();
         // ---- R4: [t; p] ----
-        auto fb4 = C::B4::fetch(gb + C::OFF_B4, wave, lane);
+        fb4 = C::B4::fetch(gb + C::OFF_B4, wave, lane);
         C::R4::run(f4, TP, wave, lane,
                    [&](int kt) { return small_gather_tile<C::R3::KS, true>(H2 + (size_t)kt * C::R3::KS * LSNF_TILE_FLOATS, lane); },
                    [&](int nt) { return lsnf_bias_init(cb + 32 * (C::P2 + C::P3 + nt), h); });
@@ -132,16 +153,42 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(cons
             small_store_tile(GV + (size_t)(HT + j) * LSNF_TILE_FLOATS, gt, lane);
         }
         __syncthreads();
+        }   // !SAVED
         // ---- B4: g_h2 = [W3s W3p][g_t; g_p] ----
         auto fb3 = C::B3::fetch(gb + C::OFF_B3, wave, lane);
-        C::B4::run(fb4, GH2, wave, lane, [&](int kt) { return tile(GTP, kt); }, [&](int) { return lsnf_zero16(); });
+        if constexpr (SAVED) {
+            // operand tile kt (< HT: g_t_kt, else g_p_{kt-HT}) built on the fly from the stashed sigma; the wave that
+            // owns output tile 0 also leaves g_v2 = g_t in GV for B1.  kt % HT == k % HT for every split of B4.
+            const bool owner = (wave / C::B4::KS) == 0;
+            C::B4::run(fb4, GH2, wave, lane,
+                       [&](int kt, int k) {
+                           const int j = kt < HT ? kt : kt - HT;                 // wave-uniform
+                           const f32x16 gy2 = tile(GX, HT + j);
+                           const f32x16& s = sg[k % HT];
+                           f32x16 o;
+                           if (kt < HT) {
+#pragma unroll
+                               for (int r = 0; r < 16; ++r) o[r] = gy2[r] * s[r];
+                               if (owner) small_store_tile(GV + (size_t)(HT + j) * LSNF_TILE_FLOATS, o, lane);
+                           } else {
+                               const f32x16 y2 = tile(Y, HT + j);
+#pragma unroll
+                               for (int r = 0; r < 16; ++r) o[r] = (1.0f - s[r]) * (gy2[r] * y2[r] + gl);
+                           }
+                           return o;
+                       },
+                       [&](int) { return lsnf_zero16(); });
+        } else {
+            C::B4::run(fb4, GH2, wave, lane, [&](int kt) { return tile(GTP, kt); }, [&](int) { return lsnf_zero16(); });
+        }
         __syncthreads();
         // ---- B3: g_h1 = W2' (g_h2 gated by h2 > 0) ----
         auto fb2 = C::B2::fetch(gb + C::OFF_B2, wave, lane);
         C::B3::run(fb3, GH1, wave, lane,
-                   [&](int kt) {
-                       return small_gate16(small_gather_tile<C::B4::KS, false>(GH2 + (size_t)kt * C::B4::KS * LSNF_TILE_FLOATS, lane),
-                                           small_gather_tile<C::R3::KS, false>(H2 + (size_t)kt * C::R3::KS * LSNF_TILE_FLOATS, lane));
+                   [&](int kt, int k) {
+                       const f32x16 gh = small_gather_tile<C::B4::KS, false>(GH2 + (size_t)kt * C::B4::KS * LSNF_TILE_FLOATS, lane);
+                       if constexpr (SAVED) return lsnf_apply_mask16(gh, mk2[k]);
+                       else return small_gate16(gh, small_gather_tile<C::R3::KS, false>(H2 + (size_t)kt * C::R3::KS * LSNF_TILE_FLOATS, lane));
                    },
                    [&](int) { return lsnf_zero16(); });
         __syncthreads();
@@ -152,14 +199,18 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(cons
         if (blk > 0 && wave < NZT)
             ynext = lsnf_load_tile<HT>(wave, a.z_saved + ((size_t)(blk - 1) * a.B + row) * a.nz, a.half, h, vec4);
         C::B2::run(fb2, GV, wave, lane,
-                   [&](int kt) {
-                       return small_gate16(small_gather_tile<C::B3::KS, false>(GH1 + (size_t)kt * C::B3::KS * LSNF_TILE_FLOATS, lane),
-                                           small_gather_tile<C::R2::KS, false>(H1 + (size_t)kt * C::R2::KS * LSNF_TILE_FLOATS, lane));
+                   [&](int kt, int k) {
+                       const f32x16 gh = small_gather_tile<C::B3::KS, false>(GH1 + (size_t)kt * C::B3::KS * LSNF_TILE_FLOATS, lane);
+                       if constexpr (SAVED) return lsnf_apply_mask16(gh, mk1[k]);
+                       else return small_gate16(gh, small_gather_tile<C::R2::KS, false>(H1 + (size_t)kt * C::R2::KS * LSNF_TILE_FLOATS, lane));
                    },
                    [&](int nt) { return tile(GX, nt); });
         __syncthreads();
         // ---- B1: g_x = Wa [g_v1; g_v2] -> GXn ----
-        if (blk > 0) f2 = C::R2::fetch(a.fwd_panels + (size_t)(blk - 1) * C::FWD_BLOCK + C::OFF_S2, wave, lane);
+        if (blk > 0) {
+            if constexpr (SAVED) { fb4 = C::B4::fetch(a.bwd_panels + (size_t)(blk - 1) * C::BWD_BLOCK + C::OFF_B4, wave, lane); fetch_act(blk - 1); }
+            else f2 = C::R2::fetch(a.fwd_panels + (size_t)(blk - 1) * C::FWD_BLOCK + C::OFF_S2, wave, lane);
+        }
         C::B1::run(fb1, GXn, wave, lane, [&](int kt) { return tile(GV, kt); }, [&](int) { return lsnf_zero16(); });
         if (blk > 0 && wave < NZT) small_store_tile(Y + (size_t)wave * LSNF_TILE_FLOATS, ynext, lane);   // Y's readers are done
         __syncthreads();
@@ -209,24 +260,29 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(cons
     }
 }
 
-template <class C>
-hipError_t launch_small_bwd(const SmallBwdArgs& a, hipStream_t stream) {
+template <class C, bool SAVED>
+hipError_t launch_small_bwd_v(const SmallBwdArgs& a, hipStream_t stream) {
     const size_t lds = ((size_t)C::T_END * LSNF_TILE_FLOATS + C::AUX_FLOATS + (size_t)a.depth * C::CONST_USED) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = lsnf_small_bwd_kernel<C>;
+    auto kern = lsnf_small_bwd_kernel<C, SAVED>;
     static unsigned long long lds_ok = 0;
     if (hipError_t e = lsnf_allow_big_lds((const void*)kern, &lds_ok); e != hipSuccess) return e;
     const unsigned grid = (unsigned)((a.B + LSNF_SMALL_SAMPLES - 1) / LSNF_SMALL_SAMPLES);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(LSNF_WG_THREADS), lds, stream, a);
     return hipGetLastError();
 }
+template <class C>
+hipError_t launch_small_bwd(const SmallBwdArgs& a, hipStream_t stream) {
+    return a.act_saved ? launch_small_bwd_v<C, true>(a, stream) : launch_small_bwd_v<C, false>(a, stream);
+}
 }  // namespace
 
 // returns hipErrorInvalidValue when the geometry's LDS footprint does not fit (caller falls back to lsnf_bwd.hip)
 hipError_t lsnf_launch_small_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
                                         const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale, float* g_z_in,
-                                        int vec4, hipStream_t stream, const LsnfLangevinArgs* lv) {
+                                        int vec4, hipStream_t stream, const LsnfLangevinArgs* lv, const float* act_saved) {
     SmallBwdArgs a;
+    a.act_saved = act_saved;
     a.fwd_consts = plan + g.off_fwd_const; a.fwd_panels = plan + g.off_fwd_panels; a.bwd_panels = plan + g.off_bwd_panels;
     a.z_out = z_out; a.z_saved = z_saved; a.g_z1 = g_z1; a.g_logdet = g_logdet; a.g_z_in = g_z_in;
     a.z_cur = nullptr; a.grad_g = nullptr; a.noise = nullptr; a.z_new = nullptr; a.gf_norm = nullptr; a.gg_norm = nullptr; a.step = 0.f;

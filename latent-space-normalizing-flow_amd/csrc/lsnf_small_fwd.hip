@@ -29,13 +29,14 @@ struct SmallFwdArgs {
     const float* consts; const float* panels;
     const float* z_in; const float* objective;
     float* z_out; float* logdet_out; float* ll_out; float* z_saved;
+    float* act_saved;      // NULL or the activation stash (already offset to first_block), lsnf_layout.h LsnfActLayout
     double* stats;
     int B, nz, half, n_blocks, vec4;
 };
 
 template <class C>
 __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_fwd_kernel(const SmallFwdArgs a) {
-    constexpr int HT = C::HT, NZT = C::NZT;
+    constexpr int HT = C::HT, NZT = C::NZT, WT = C::WT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tiles = smem;                                            // C::T_END tiles
     float* aux = smem + (size_t)C::T_END * LSNF_TILE_FLOATS;         // AUX_FLOATS
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_fwd_kernel(cons
                                      lsnf_load_tile<HT>(wave, a.z_in + row * (long)a.nz, a.half, h, vec4), lane);
     float ell = 0.0f;                                               // carried by wave 0
     if (wave == 0) ell = a.objective ? a.objective[row] : 0.0f;
+    const LsnfActLayout al = lsnf_act_layout(a.B, HT, WT);
     __syncthreads();
 
     for (int blk = 0; blk < a.n_blocks; ++blk) {
@@ -67,6 +69,7 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_fwd_kernel(cons
         float* H1 = tiles + (size_t)C::T_H1 * LSNF_TILE_FLOATS;
         float* H2 = tiles + (size_t)C::T_H2 * LSNF_TILE_FLOATS;
         float* TP = tiles + (size_t)C::T_TP * LSNF_TILE_FLOATS;
+        float* act = a.act_saved ? a.act_saved + (size_t)blk * al.per_block + (size_t)blockIdx.x * al.per_tile : nullptr;
 
         // ---- S1 (actnorm + 1x1 conv, model.py:244,268,187); weights of S2 fetched meanwhile ----
         auto f2 = C::S2::fetch(gblk + C::OFF_S2, wave, lane);
@@ -85,12 +88,18 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_fwd_kernel(cons
         __syncthreads();
         // ---- S3 ----
         auto f4 = C::S4::fetch(gblk + C::OFF_S4, wave, lane);
+        if (act && wave < WT)   // relu mask of h1 tile `wave` for the backward (model.py:307)
+            *lsnf_act_mask_ptr(act, al.mask_off, wave, lane) =
+                lsnf_posmask16(small_gather_tile<C::S2::KS, false>(H1 + (size_t)wave * C::S2::KS * LSNF_TILE_FLOATS, lane));
         C::S3::run(f3, H2, wave, lane,
                    [&](int kt) { return small_gather_tile<C::S2::KS, true>(H1 + (size_t)kt * C::S2::KS * LSNF_TILE_FLOATS, lane); },
                    [&](int nt) { return lsnf_bias_init(cb + 32 * (C::P1 + C::P2 + nt), h); });
         __syncthreads();
         // ---- S4 (fc_zeros, shift / pre-sigmoid de-interleaved, model.py:347-349,411-413) ----
         if (more) f1 = C::S1::fetch(gblk + C::BLOCK_FLOATS, wave, lane);
+        if (act && wave < WT)
+            *lsnf_act_mask_ptr(act, al.mask_off, WT + wave, lane) =
+                lsnf_posmask16(small_gather_tile<C::S3::KS, false>(H2 + (size_t)wave * C::S3::KS * LSNF_TILE_FLOATS, lane));
         C::S4::run(f4, TP, wave, lane,
                    [&](int kt) { return small_gather_tile<C::S3::KS, true>(H2 + (size_t)kt * C::S3::KS * LSNF_TILE_FLOATS, lane); },
                    [&](int nt) { return lsnf_bias_init(cb + 32 * (C::P1 + C::P2 + C::P3 + nt), h); });
@@ -102,15 +111,17 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_fwd_kernel(cons
             const f32x16 v2 = small_gather_tile<C::S1::KS, false>(V + (size_t)(HT + j) * C::S1::KS * LSNF_TILE_FLOATS, lane);
             const f32x16 t = small_gather_tile<C::S4::KS, false>(TP + (size_t)j * C::S4::KS * LSNF_TILE_FLOATS, lane);
             const f32x16 p = small_gather_tile<C::S4::KS, false>(TP + (size_t)(HT + j) * C::S4::KS * LSNF_TILE_FLOATS, lane);
-            f32x16 y;
+            f32x16 y, sg;
             float lsum = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float sig, l2;
                 lsnf_sigmoid_log2(p[r], sig, l2);
                 y[r] = (v2[r] + t[r]) * sig;
+                sg[r] = sig;
                 lsum += l2;
             }
+            if (act) lsnf_act_store_sigma(act, j, sg, lane);
             small_store_tile(Xn + (size_t)(HT + j) * LSNF_TILE_FLOATS, y, lane);
             aux[64 * j + lane] = lsum;
         } else if (wave < 2 * HT) {
@@ -176,11 +187,13 @@ hipError_t launch_small_fwd(const SmallFwdArgs& a, hipStream_t stream) {
 
 hipError_t lsnf_launch_small_forward(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                      const float* z_in, const float* objective, float* z_out, float* logdet_out,
-                                     float* ll_out, float* z_saved, double* stats, int vec4, hipStream_t stream) {
+                                     float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
+                                     hipStream_t stream) {
     SmallFwdArgs a;
     a.consts = plan + g.off_fwd_const + (size_t)first_block * g.fwd_const_floats;
     a.panels = plan + g.off_fwd_panels + (size_t)first_block * g.fwd_block_floats;
     a.z_in = z_in; a.objective = objective; a.z_out = z_out; a.logdet_out = logdet_out; a.ll_out = ll_out;
+    a.act_saved = act_saved ? act_saved + (size_t)first_block * lsnf_act_layout(B, g.HT, g.WT).per_block : nullptr;
     a.z_saved = z_saved; a.stats = stats; a.B = B; a.nz = g.nz; a.half = g.half; a.n_blocks = n_blocks; a.vec4 = vec4;
     if (g.HT == 1 && g.WT == 1) return launch_small_fwd<SmallFwdCfg<1, 1>>(a, stream);
     if (g.HT == 2 && g.WT == 2) return launch_small_fwd<SmallFwdCfg<2, 2>>(a, stream);

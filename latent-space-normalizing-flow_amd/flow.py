@@ -123,9 +123,11 @@ def params_from_state_dict(sd, depth: int, device=None) -> List[torch.Tensor]:
 def forward(plan: FlowPlan, z: torch.Tensor, objective: Optional[torch.Tensor] = None, *,
             first_block: int = 0, n_blocks: Optional[int] = None, want_ll: bool = True,
             save_for_backward: bool = False, out: Optional[Tuple[torch.Tensor, ...]] = None,
-            stats: Optional[torch.Tensor] = None):
+            stats: Optional[torch.Tensor] = None, act_saved: Optional[torch.Tensor] = None):
     """One launch: blocks [first_block, first_block+n_blocks) on (B, nz) rows.
     Returns (z_out, logdet, ll or None, z_saved or None).  model.py:473-483 + train.py:317-319.
+    act_saved: optional buffer from `new_act_saved()`, filled with the sigmoid / relu-mask stash that lets
+    `backward_z` / the Langevin step skip recomputing the coupling MLP.
     stats: optional buffer from `new_stats()`; afterwards stats[4] = sum ll, stats[5] = sum logdet, stats[6] = B
     (summed inside the kernel -- no separate reduction launch)."""
     lib = _lib.load()
@@ -150,7 +152,7 @@ def forward(plan: FlowPlan, z: torch.Tensor, objective: Optional[torch.Tensor] =
     with torch.cuda.device(z.device):
         rc = lib.lsnf_forward(_ptr(plan.buf), plan.nz, plan.width, plan.depth, plan.coupling, first_block, n_blocks, B,
                               _ptr(z), _ptr(objective), _ptr(z_out), _ptr(logdet), _ptr(ll), _ptr(saved),
-                              _ptr(stats), _stream_ptr(z.device))
+                              _ptr(act_saved), _ptr(stats), _stream_ptr(z.device))
     _lib.check(rc, "lsnf_forward")
     return z_out, logdet, ll, saved
 
@@ -158,6 +160,12 @@ def forward(plan: FlowPlan, z: torch.Tensor, objective: Optional[torch.Tensor] =
 def set_small_batch_max(rows: int) -> int:
     """Batches <= rows use the small-batch (latency) kernels; returns the previous threshold (rows < 0: query)."""
     return _lib.load().lsnf_set_small_batch_max(int(rows))
+
+
+def new_act_saved(plan: "FlowPlan", B: int, device) -> torch.Tensor:
+    """Uninitialised activation stash for `forward(..., act_saved=)` on a batch of B rows."""
+    n = _lib.load().lsnf_act_saved_floats(plan.nz, plan.width, plan.depth, int(B))
+    return torch.empty(max(n, 1), dtype=torch.float32, device=device)
 
 
 def new_stats(device) -> torch.Tensor:
@@ -185,19 +193,20 @@ def reverse(plan: FlowPlan, z: torch.Tensor, objective: Optional[torch.Tensor] =
 
 def backward_z(plan: FlowPlan, z_out: torch.Tensor, z_saved: Optional[torch.Tensor],
                g_z1: Optional[torch.Tensor] = None, g_logdet: Optional[torch.Tensor] = None,
-               ll_scale: Optional[float] = None) -> torch.Tensor:
+               ll_scale: Optional[float] = None, act_saved: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dL/dz_in of the full stack (train.py:323).  Either pass upstream gradients (g_z1, g_logdet) or
-    ll_scale for L = ll_scale * sum_b ll_b (train.py:320: ll_scale = -1)."""
+    ll_scale for L = ll_scale * sum_b ll_b (train.py:320: ll_scale = -1).  act_saved: the stash the forward
+    filled (same batch), or None to recompute the coupling MLP from z_saved."""
     lib = _lib.load()
     _need_cuda(z_out, "z_out")
     B = z_out.shape[0]
-    for name, t in (("z_saved", z_saved), ("g_z1", g_z1), ("g_logdet", g_logdet)):
+    for name, t in (("z_saved", z_saved), ("g_z1", g_z1), ("g_logdet", g_logdet), ("act_saved", act_saved)):
         if t is not None:
             _need_cuda(t, name)
     g_in = torch.empty_like(z_out)
     with torch.cuda.device(z_out.device):
         rc = lib.lsnf_backward_z(_ptr(plan.buf), plan.nz, plan.width, plan.depth, plan.coupling, B,
-                                 _ptr(z_out), _ptr(z_saved), _ptr(g_z1), _ptr(g_logdet),
+                                 _ptr(z_out), _ptr(z_saved), _ptr(act_saved), _ptr(g_z1), _ptr(g_logdet),
                                  0 if ll_scale is None else 1, float(ll_scale or 0.0), _ptr(g_in),
                                  _stream_ptr(z_out.device))
     _lib.check(rc, "lsnf_backward_z")
@@ -217,13 +226,14 @@ def langevin_step(plan: FlowPlan, z: torch.Tensor, grad_g: Optional[torch.Tensor
             _need_cuda(t, name)
             if t.shape != z.shape:
                 raise LsnfError(f"{name} must have the shape of z")
-    z1, logdet, ll, saved = forward(plan, z, None, want_ll=True, save_for_backward=True)
+    act = new_act_saved(plan, B, z.device)
+    z1, logdet, ll, saved = forward(plan, z, None, want_ll=True, save_for_backward=True, act_saved=act)
     z_new = z if inplace else torch.empty_like(z)
     gf = torch.empty(B, dtype=torch.float32, device=z.device) if want_norms else None
     gg = torch.empty(B, dtype=torch.float32, device=z.device) if (want_norms and grad_g is not None) else None
     with torch.cuda.device(z.device):
         rc = lib.lsnf_langevin_step(_ptr(plan.buf), plan.nz, plan.width, plan.depth, plan.coupling, B,
-                                    _ptr(z), _ptr(z1), _ptr(saved), _ptr(grad_g), _ptr(noise), float(step_size),
+                                    _ptr(z), _ptr(z1), _ptr(saved), _ptr(act), _ptr(grad_g), _ptr(noise), float(step_size),
                                     _ptr(z_new), _ptr(gf), _ptr(gg), _stream_ptr(z.device))
     _lib.check(rc, "lsnf_langevin_step")
     return z_new, ll, gf, gg

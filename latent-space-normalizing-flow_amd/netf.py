@@ -141,9 +141,13 @@ class _FlowStackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, holder, z, objective, token):
         plan = module._plan()
-        z1, logdet, _, saved = flow.forward(plan, z, objective, want_ll=False, save_for_backward=True)
+        # z needs a gradient (the Langevin sampler, train.py:316-323): also keep the sigmoid / relu-mask stash so
+        # that lsnf_backward_z does not recompute the coupling MLP
+        act = flow.new_act_saved(plan, z.shape[0], z.device) if (ctx.needs_input_grad[2] and z.shape[0]) else None
+        z1, logdet, _, saved = flow.forward(plan, z, objective, want_ll=False, save_for_backward=True, act_saved=act)
         ctx.module, ctx.holder = module, holder
         ctx.plan_key = module._plan_key
+        ctx.act = act
         ctx.save_for_backward(z, z1, saved if saved is not None else z1.new_empty(0))
         return z1, logdet
 
@@ -156,7 +160,7 @@ class _FlowStackFn(torch.autograd.Function):
         saved_t = saved if saved.numel() else None
         g_z1 = None if g_z1 is None else g_z1.contiguous()
         g_logdet = None if g_logdet is None else g_logdet.contiguous()
-        g_z = flow.backward_z(module._plan(), z1, saved_t, g_z1, g_logdet) if ctx.needs_input_grad[2] else None
+        g_z = flow.backward_z(module._plan(), z1, saved_t, g_z1, g_logdet, act_saved=ctx.act) if ctx.needs_input_grad[2] else None
         g_obj = g_logdet if ctx.needs_input_grad[3] else None
         g_tok = None
         if ctx.needs_input_grad[4]:
@@ -253,8 +257,10 @@ class _netF(nn.Module):
     def log_prob_and_grad(self, z, scale=-1.0):
         """ll and d(scale * sum ll)/dz (train.py:320-323 uses scale = -1), two launches."""
         plan = self._plan()
-        z1, logdet, ll, saved = flow.forward(plan, z.detach().contiguous(), None, want_ll=True, save_for_backward=True)
-        g = flow.backward_z(plan, z1, saved, ll_scale=scale)
+        act = flow.new_act_saved(plan, z.shape[0], z.device)
+        z1, logdet, ll, saved = flow.forward(plan, z.detach().contiguous(), None, want_ll=True, save_for_backward=True,
+                                             act_saved=act)
+        g = flow.backward_z(plan, z1, saved, ll_scale=scale, act_saved=act)
         return ll, g
 
     def langevin_step(self, z, grad_g=None, noise=None, step_size=0.1, inplace=False):

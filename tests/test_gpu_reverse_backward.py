@@ -18,6 +18,19 @@ def lsnf():
     return lsnf_amd
 
 
+@pytest.fixture(params=["recompute", "act-stash"])
+def stash(request):
+    """The backward either recomputes the coupling MLP from z_saved or reads the forward's activation stash."""
+    return request.param == "act-stash"
+
+
+def _fwd(lsnf, plan, z, stash, **kw):
+    act = lsnf.flow.new_act_saved(plan, z.shape[0], z.device) if stash else None
+    if act is not None:
+        act.fill_(float("nan"))      # every word the backward reads must have been written by the forward
+    return (*lsnf.forward(plan, z, save_for_backward=True, act_saved=act, **kw), act)
+
+
 def _plan(lsnf, p, g, dev):
     nz, w, d = int(g["meta_nz"]), int(g["meta_width"]), int(g["meta_depth"])
     return lsnf.prepare(lsnf.params_from_state_dict(p, d, dev), nz, w, d, int(g.get("meta_coupling", 1)))
@@ -48,13 +61,14 @@ def test_roundtrip_forward_reverse(lsnf, kernels, gpu_device, name):
 
 
 @pytest.mark.parametrize("name", golden_names())
-def test_grad_z_matches_reference_golden(lsnf, kernels, gpu_device, name):
+def test_grad_z_matches_reference_golden(lsnf, kernels, stash, gpu_device, name):
     """d(-sum ll)/dz (train.py:320-323), fused ll_mode."""
     p, g = load_golden(name)
     plan = _plan(lsnf, p, g, gpu_device)
     z = torch.from_numpy(g["z"]).to(gpu_device)
-    z1, ld, ll, saved = lsnf.forward(plan, z, save_for_backward=True)
-    gz = lsnf.backward_z(plan, z1, saved, ll_scale=-1.0).cpu().numpy()
+    z1, ld, ll, saved, act = _fwd(lsnf, plan, z, stash)
+    assert np.max(np.abs(ll.cpu().numpy() - g["ll"]) / np.maximum(np.abs(g["ll"]), 1.0)) <= 1e-5
+    gz = lsnf.backward_z(plan, z1, saved, ll_scale=-1.0, act_saved=act).cpu().numpy()
     ref = g["grad_z"]
     # rows sitting on a ReLU kink (float64 pre-activation < 2e-6) have no well-defined fp32 gradient
     ok = (O.relu_margin(p, torch.from_numpy(g["z"])) > KINK).numpy()
@@ -66,7 +80,7 @@ def test_grad_z_matches_reference_golden(lsnf, kernels, gpu_device, name):
 
 
 @pytest.mark.parametrize("nz,width,B", [(128, 64, 130), (100, 64, 77), (100, 128, 50), (20, 10, 33), (2, 1, 3)])
-def test_backward_general_upstream_vs_oracle(lsnf, kernels, gpu_device, nz, width, B):
+def test_backward_general_upstream_vs_oracle(lsnf, kernels, stash, gpu_device, nz, width, B):
     """Arbitrary upstream gradients (g_z1, g_logdet) against autograd over the oracle."""
     depth = 5
     p = O.init_params(nz, width, depth, seed=3 * nz + width)
@@ -78,14 +92,14 @@ def test_backward_general_upstream_vs_oracle(lsnf, kernels, gpu_device, nz, widt
     z1r, ldr = O.flow_forward(p, zz, torch.zeros(B))
     (ref,) = torch.autograd.grad((z1r * gz1).sum() + (ldr * gld).sum(), zz)
     plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
-    z1, ld, _, saved = lsnf.forward(plan, z.to(gpu_device), save_for_backward=True, want_ll=False)
+    z1, ld, _, saved, act = _fwd(lsnf, plan, z.to(gpu_device), stash, want_ll=False)
     ok = O.relu_margin(p, z) > KINK
-    got = lsnf.backward_z(plan, z1, saved, gz1.to(gpu_device), gld.to(gpu_device)).cpu()
+    got = lsnf.backward_z(plan, z1, saved, gz1.to(gpu_device), gld.to(gpu_device), act_saved=act).cpu()
     assert ((got - ref)[ok].norm() / ref[ok].norm()).item() <= 1e-5
     # only one of the two upstream gradients
     z1r, ldr = O.flow_forward(p, zz, torch.zeros(B))
     (ref2,) = torch.autograd.grad((ldr * gld).sum(), zz)
-    got2 = lsnf.backward_z(plan, z1, saved, None, gld.to(gpu_device)).cpu()
+    got2 = lsnf.backward_z(plan, z1, saved, None, gld.to(gpu_device), act_saved=act).cpu()
     assert ((got2 - ref2)[ok].norm() / ref2[ok].norm()).item() <= 1e-5
 
 
@@ -124,3 +138,12 @@ def test_full_size_backward_properties(lsnf, gpu_device):
     ref = O.grad_neg_sum_ll_wrt_z(p, z[idx])
     ok = O.relu_margin(p, z[idx]) > KINK
     assert ((g.cpu()[idx] - ref)[ok].norm() / ref[ok].norm()).item() <= 1e-5
+    # (d) the activation-stash backward agrees with the recomputing one (8-wave forward writes, 4-wave backward reads)
+    z1b, _, llb, savedb, act = _fwd(lsnf, plan, zd, True)
+    assert torch.equal(z1b, z1) and torch.equal(llb, ll)
+    gs = lsnf.backward_z(plan, z1b, savedb, ll_scale=-1.0, act_saved=act)
+    assert (gs - g).abs().max().item() <= 2e-5 * g.abs().max().item()
+    B2 = 40000 + 17                                  # ragged tail: last workgroup has idle waves
+    z1c, _, _, savedc, actc = _fwd(lsnf, plan, zd[:B2].contiguous(), True)
+    gc = lsnf.backward_z(plan, z1c, savedc, ll_scale=-1.0, act_saved=actc)
+    assert (gc - g[:B2]).abs().max().item() <= 2e-5 * g.abs().max().item()

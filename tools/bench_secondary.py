@@ -41,6 +41,9 @@ for (tag, nz, w, B) in [("C2/C4 SVHN/CelebA nz=100 w=64 B=100", 100, 64, 100), (
     z1, ld, ll, saved = lsnf_amd.forward(plan, z, save_for_backward=True)
     r["forward_saving_us"] = timeit(lambda: lsnf_amd.forward(plan, z, save_for_backward=True), n)
     r["backward_z_us"] = timeit(lambda: lsnf_amd.backward_z(plan, z1, saved, ll_scale=-1.0), n)
+    act = lsnf_amd.flow.new_act_saved(plan, B, dev)
+    r["forward_saving_with_act_stash_us"] = timeit(lambda: lsnf_amd.forward(plan, z, save_for_backward=True, act_saved=act), n)
+    r["backward_z_from_act_stash_us"] = timeit(lambda: lsnf_amd.backward_z(plan, z1, saved, ll_scale=-1.0, act_saved=act), n)
     r["langevin_step_fwd_plus_fused_update_us"] = timeit(lambda: net.langevin_step(z, gg, noise, 0.1), n)
     r["reverse_us"] = timeit(lambda: lsnf_amd.reverse(plan, z), n)
     def mle():
