@@ -35,11 +35,13 @@ hipError_t lsnf_launch_small_reverse(const LsnfGeo& g, const float* plan, int B,
                                      float* z_out, float* objective_out, int vec4, hipStream_t stream);
 hipError_t lsnf_launch_small_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
                                         const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale, float* g_z_in,
-                                        int vec4, hipStream_t stream, const LsnfLangevinArgs* lv, const float* act_saved);
+                                        int vec4, hipStream_t stream, const LsnfLangevinArgs* lv, const float* act_saved,
+                                        float* dump = nullptr, float* gl_total = nullptr);
 hipError_t lsnf_launch_backward_params(const LsnfGeo& g, const float* plan, const float* const* params_host,
                                        float* const* grads_host, int B, const float* z_in, const float* z_out,
                                        const float* z_saved, const float* g_z1, const float* g_logdet, int ll_mode,
-                                       float ll_scale, float* g_z_in, float* workspace, int vec4, hipStream_t stream);
+                                       float ll_scale, float* g_z_in, float* workspace, int vec4, int small_batch,
+                                       hipStream_t stream);
 
 namespace {
 thread_local char g_err[512] = "";
@@ -259,7 +261,8 @@ int lsnf_backward_params(const float* plan, const float* const* params_host, flo
         return fail(LSNF_E_ARG, "lsnf_backward_params: tensors must be 4-byte aligned");
     const int vec4 = row_vector_width(g, {z_out, g_z_in, z_saved, g_z1});
     hipError_t e = lsnf_launch_backward_params(g, plan, params_host, grads_host, B, z_in, z_out, z_saved, g_z1, g_logdet,
-                                               ll_mode, ll_scale, g_z_in, workspace, vec4, (hipStream_t)stream);
+                                               ll_mode, ll_scale, g_z_in, workspace, vec4, B <= small_batch_max(),
+                                               (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "lsnf_backward_params launch");
     return LSNF_OK;
 }

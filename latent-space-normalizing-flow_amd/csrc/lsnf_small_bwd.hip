@@ -10,6 +10,9 @@
 //   B2       : g_v1 = g_v1 + W1'(g_h1 * [h1>0]) B1 : g_x  = Wa [g_v1; g_v2]
 // SAVED variant (the forward filled act_saved): R2..R4 disappear, sigma and the relu masks come from the stash,
 // and CB is folded into B4's operand fetch -- 4 stages per block instead of 8.
+// DUMP variant (parameter gradients, lsnf_params.hip): the recomputing kernel additionally writes, per block, the
+// per-sample tensors of LsnfDumpLayout (h1, h2, g_a1, g_a2, g_t, g_p, g_v) -- each tile by the one wave that
+// owns output tile 0 of the stage consuming it -- and accumulates sum_b dL/dlogdet_b.
 #include "lsnf_small.h"
 
 namespace {
@@ -46,13 +49,32 @@ struct SmallBwdArgs {
     const float* fwd_consts; const float* fwd_panels; const float* bwd_panels;
     const float* z_out; const float* z_saved; const float* act_saved; const float* g_z1; const float* g_logdet;
     float* g_z_in;
+    float* dump; float* gl_total;      // DUMP variant only
     const float* z_cur; const float* grad_g; const float* noise; float* z_new; float* gf_norm; float* gg_norm;
     float step, ll_scale;
-    int ll_mode, B, nz, half, depth, vec4;
+    int ll_mode, B, nz, half, width, depth, vec4;
 };
 
-template <class C, bool SAVED>
+// one plain-pad tile (feature f = 32*t + o(r,h), valid f < ncols) -> dense (B, ncols) row-major
+__device__ __forceinline__ void small_store_plain(const f32x16& x, float* __restrict__ dst, long row, int ncols, int t, int h) {
+    float* d = dst + row * (long)ncols;
+    const bool v4 = (ncols & 3) == 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int f0 = 32 * t + 8 * g + 4 * h;
+        if (v4) {
+            if (f0 < ncols) { f32x4 v = {x[4 * g + 0], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]}; *reinterpret_cast<f32x4*>(d + f0) = v; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (f0 + j < ncols) d[f0 + j] = x[4 * g + j];
+        }
+    }
+}
+
+template <class C, bool SAVED, bool DUMP>
 __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(const SmallBwdArgs a) {
+    static_assert(!(DUMP && SAVED), "the parameter-gradient dump needs the recomputed activations");
     constexpr int HT = C::HT, NZT = C::NZT, WT = C::WT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tiles = smem;
@@ -95,6 +117,15 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(cons
     // upstream gradient -> GX[parity of last block], block output of the last block -> Y
     float gl;
     if (a.ll_mode) gl = a.ll_scale; else gl = a.g_logdet ? a.g_logdet[row] : 0.0f;
+    const LsnfDumpLayout dl = lsnf_dump_layout(a.B, a.nz, a.width);
+    if constexpr (DUMP) {   // G = sum_b dL/dlogdet_b : one atomic per workgroup
+        if (wave == 0) {
+            float t = (live && h == 0) ? gl : 0.0f;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+            if (lane == 0) atomicAdd(a.gl_total, t);
+        }
+    }
     if (wave < NZT) {
         const f32x16 y = lsnf_load_tile<HT>(wave, a.z_out + row * (long)a.nz, a.half, h, vec4);
         small_store_tile(T(C::T_Y + wave), y, lane);
@@ -117,6 +148,7 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(cons
         float* Y = T(C::T_Y); float* H1 = T(C::T_H1); float* H2 = T(C::T_H2); float* TP = T(C::T_TP);
         float* GTP = T(C::T_GTP); float* GH2 = T(C::T_GH2); float* GH1 = T(C::T_GH1); float* GV = T(C::T_GV);
         auto tile = [&](const float* base, int t) { return small_load_tile(base + (size_t)t * LSNF_TILE_FLOATS, lane); };
+        float* dmp = DUMP ? a.dump + (size_t)blk * dl.per_block : nullptr;
 
         if constexpr (!SAVED) {
         // ---- R2: h1 = W1'^T v1 + c1 ----
@@ -151,6 +183,9 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(cons
             small_store_tile(GTP + (size_t)j * LSNF_TILE_FLOATS, gt, lane);
             small_store_tile(GTP + (size_t)(HT + j) * LSNF_TILE_FLOATS, gp, lane);
             small_store_tile(GV + (size_t)(HT + j) * LSNF_TILE_FLOATS, gt, lane);
+            if constexpr (DUMP) {
+                if (live) { small_store_plain(gt, dmp + dl.off_gt, sample, a.half, j, h); small_store_plain(gp, dmp + dl.off_gp, sample, a.half, j, h); }
+            }
         }
         __syncthreads();
         }   // !SAVED
@@ -188,7 +223,17 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(cons
                    [&](int kt, int k) {
                        const f32x16 gh = small_gather_tile<C::B4::KS, false>(GH2 + (size_t)kt * C::B4::KS * LSNF_TILE_FLOATS, lane);
                        if constexpr (SAVED) return lsnf_apply_mask16(gh, mk2[k]);
-                       else return small_gate16(gh, small_gather_tile<C::R3::KS, false>(H2 + (size_t)kt * C::R3::KS * LSNF_TILE_FLOATS, lane));
+                       else {
+                           const f32x16 pre = small_gather_tile<C::R3::KS, false>(H2 + (size_t)kt * C::R3::KS * LSNF_TILE_FLOATS, lane);
+                           const f32x16 ga = small_gate16(gh, pre);
+                           if constexpr (DUMP) {
+                               if (live && wave / C::B3::KS == 0) {
+                                   small_store_plain(lsnf_relu16(pre), dmp + dl.off_h2, sample, a.width, kt, h);
+                                   small_store_plain(ga, dmp + dl.off_ga2, sample, a.width, kt, h);
+                               }
+                           }
+                           return ga;
+                       }
                    },
                    [&](int) { return lsnf_zero16(); });
         __syncthreads();
@@ -202,7 +247,17 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(cons
                    [&](int kt, int k) {
                        const f32x16 gh = small_gather_tile<C::B3::KS, false>(GH1 + (size_t)kt * C::B3::KS * LSNF_TILE_FLOATS, lane);
                        if constexpr (SAVED) return lsnf_apply_mask16(gh, mk1[k]);
-                       else return small_gate16(gh, small_gather_tile<C::R2::KS, false>(H1 + (size_t)kt * C::R2::KS * LSNF_TILE_FLOATS, lane));
+                       else {
+                           const f32x16 pre = small_gather_tile<C::R2::KS, false>(H1 + (size_t)kt * C::R2::KS * LSNF_TILE_FLOATS, lane);
+                           const f32x16 ga = small_gate16(gh, pre);
+                           if constexpr (DUMP) {
+                               if (live && wave == 0) {       // B2 is unsplit: wave 0 owns output tile 0
+                                   small_store_plain(lsnf_relu16(pre), dmp + dl.off_h1, sample, a.width, kt, h);
+                                   small_store_plain(ga, dmp + dl.off_ga1, sample, a.width, kt, h);
+                               }
+                           }
+                           return ga;
+                       }
                    },
                    [&](int nt) { return tile(GX, nt); });
         __syncthreads();
@@ -211,7 +266,15 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(cons
             if constexpr (SAVED) { fb4 = C::B4::fetch(a.bwd_panels + (size_t)(blk - 1) * C::BWD_BLOCK + C::OFF_B4, wave, lane); fetch_act(blk - 1); }
             else f2 = C::R2::fetch(a.fwd_panels + (size_t)(blk - 1) * C::FWD_BLOCK + C::OFF_S2, wave, lane);
         }
-        C::B1::run(fb1, GXn, wave, lane, [&](int kt) { return tile(GV, kt); }, [&](int) { return lsnf_zero16(); });
+        C::B1::run(fb1, GXn, wave, lane,
+                   [&](int kt) {
+                       const f32x16 gvt = tile(GV, kt);
+                       if constexpr (DUMP) {
+                           if (live && wave == 0) lsnf_store_tile<HT>(kt, gvt, dmp + dl.off_gv + sample * (long)a.nz, a.half, h, vec4);
+                       }
+                       return gvt;
+                   },
+                   [&](int) { return lsnf_zero16(); });
         if (blk > 0 && wave < NZT) small_store_tile(Y + (size_t)wave * LSNF_TILE_FLOATS, ynext, lane);   // Y's readers are done
         __syncthreads();
     }
@@ -260,11 +323,11 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(cons
     }
 }
 
-template <class C, bool SAVED>
+template <class C, bool SAVED, bool DUMP>
 hipError_t launch_small_bwd_v(const SmallBwdArgs& a, hipStream_t stream) {
     const size_t lds = ((size_t)C::T_END * LSNF_TILE_FLOATS + C::AUX_FLOATS + (size_t)a.depth * C::CONST_USED) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = lsnf_small_bwd_kernel<C, SAVED>;
+    auto kern = lsnf_small_bwd_kernel<C, SAVED, DUMP>;
     static unsigned long long lds_ok = 0;
     if (hipError_t e = lsnf_allow_big_lds((const void*)kern, &lds_ok); e != hipSuccess) return e;
     const unsigned grid = (unsigned)((a.B + LSNF_SMALL_SAMPLES - 1) / LSNF_SMALL_SAMPLES);
@@ -273,16 +336,19 @@ hipError_t launch_small_bwd_v(const SmallBwdArgs& a, hipStream_t stream) {
 }
 template <class C>
 hipError_t launch_small_bwd(const SmallBwdArgs& a, hipStream_t stream) {
-    return a.act_saved ? launch_small_bwd_v<C, true>(a, stream) : launch_small_bwd_v<C, false>(a, stream);
+    if (a.dump) return launch_small_bwd_v<C, false, true>(a, stream);
+    return a.act_saved ? launch_small_bwd_v<C, true, false>(a, stream) : launch_small_bwd_v<C, false, false>(a, stream);
 }
 }  // namespace
 
 // returns hipErrorInvalidValue when the geometry's LDS footprint does not fit (caller falls back to lsnf_bwd.hip)
 hipError_t lsnf_launch_small_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
                                         const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale, float* g_z_in,
-                                        int vec4, hipStream_t stream, const LsnfLangevinArgs* lv, const float* act_saved) {
+                                        int vec4, hipStream_t stream, const LsnfLangevinArgs* lv, const float* act_saved,
+                                        float* dump, float* gl_total) {
     SmallBwdArgs a;
-    a.act_saved = act_saved;
+    a.act_saved = dump ? nullptr : act_saved;
+    a.dump = dump; a.gl_total = gl_total; a.width = g.width;
     a.fwd_consts = plan + g.off_fwd_const; a.fwd_panels = plan + g.off_fwd_panels; a.bwd_panels = plan + g.off_bwd_panels;
     a.z_out = z_out; a.z_saved = z_saved; a.g_z1 = g_z1; a.g_logdet = g_logdet; a.g_z_in = g_z_in;
     a.z_cur = nullptr; a.grad_g = nullptr; a.noise = nullptr; a.z_new = nullptr; a.gf_norm = nullptr; a.gg_norm = nullptr; a.step = 0.f;

@@ -39,9 +39,18 @@ def sample_langevin_post_z_with_flow(z, x, netG: nn.Module, netF, *, g_l_steps: 
     return z.detach(), gg_norm, gf_norm, f_log_lkhd
 
 
-def flow_mle_step(netF, optF, z_g_k, f_max_norm: Optional[float] = None):
-    """train.py:404-415: one Adam step of the flow on the Langevin-inferred z.  Returns loss_f (detached)."""
+def flow_mle_step(netF, optF, z_g_k, f_max_norm: Optional[float] = None, fused: bool = False):
+    """train.py:404-415: one Adam step of the flow on the Langevin-inferred z.  Returns loss_f (detached).
+    fused=False restates the reference line by line (autograd through `netF(...)`); fused=True computes the same
+    loss and gradients with `netF.mle_grads` (no autograd graph, no element-wise torch launches)."""
     import numpy as np
+    if fused:
+        optF.zero_grad(set_to_none=True)
+        loss_f = netF.mle_grads(z_g_k.reshape(z_g_k.shape[0], -1))
+        if f_max_norm is not None:
+            torch.nn.utils.clip_grad_norm_(netF.parameters(), f_max_norm)
+        optF.step()
+        return loss_f
     optF.zero_grad()
     z2d = torch.squeeze(z_g_k)
     z1, logdet, _ = netF(z2d, objective=torch.zeros(int(z_g_k.shape[0]), device=z2d.device), init=False)

@@ -269,3 +269,22 @@ class _netF(nn.Module):
         return flow.langevin_step(self._plan(), z.detach().contiguous(),
                                   None if grad_g is None else grad_g.detach().contiguous(),
                                   None if noise is None else noise.detach().contiguous(), step_size, inplace=inplace)
+
+    def mle_grads(self, z, accumulate: bool = False):
+        """Fused flow-MLE gradients (train.py:404-411): loss_f = -mean_b ll(z_b) and d loss_f / d theta written to
+        `.grad` of the 60 live tensors -- forward (ll summed in-kernel), dump backward, batch contraction, unfold:
+        5 launches and no autograd graph.  Returns loss_f as a 0-dim device tensor (no host sync)."""
+        plan = self._plan()
+        z = z.detach().contiguous()
+        B = z.shape[0]
+        if B == 0:
+            raise LsnfError("mle_grads needs a non-empty batch")
+        stats = flow.new_stats(z.device)
+        z1, _, _, saved = flow.forward(plan, z, None, want_ll=False, save_for_backward=True, stats=stats)
+        params = self._param_list()
+        grads = flow.backward_params(plan, params, z, z1, saved, ll_scale=-1.0 / B)
+        for p, g in zip(params, grads):
+            if not p.requires_grad:
+                continue
+            p.grad = g if (p.grad is None or not accumulate) else p.grad + g
+        return (stats[4] * (-1.0 / B)).to(torch.float32)

@@ -117,3 +117,23 @@ def test_sampler_and_mle_step_harness_vs_oracle(lsnf, gpu_device):
     for _ in range(5):
         l1 = lsnf.langevin.flow_mle_step(net, opt, zk, f_max_norm=100.0)
     assert l1.item() < l0.item()
+    # the fused step (netF.mle_grads) computes the same loss and gradients as the autograd restatement
+    net.zero_grad(set_to_none=True)
+    z2d = zk.reshape(B, nz)
+    z1, ld, _ = net(z2d, objective=torch.zeros(B, device=gpu_device))
+    loss_a = -(-0.5 * (z1 ** 2).sum(1) + float(np.log(2 * np.pi)) + ld).mean()
+    loss_a.backward()
+    ref = {k: v.grad.clone() for k, v in net.named_parameters() if v.grad is not None}
+    net.zero_grad(set_to_none=True)
+    loss_b = net.mle_grads(z2d)
+    assert abs(loss_a.item() - loss_b.item()) <= 2e-6 * abs(loss_a.item())
+    got = {k: v.grad for k, v in net.named_parameters() if v.grad is not None}
+    assert set(got) == set(ref) and len(ref) == 60
+    for k in ref:
+        assert (got[k] - ref[k]).norm().item() <= 1e-5 * max(ref[k].norm().item(), 1e-3), k
+    net.mle_grads(z2d, accumulate=True)
+    for k in ref:
+        assert (net.get_parameter(k).grad - 2 * ref[k]).norm().item() <= 2e-5 * max(ref[k].norm().item(), 1e-3), k
+    l2 = lsnf.langevin.flow_mle_step(net, opt, zk, f_max_norm=100.0, fused=True)
+    l3 = lsnf.langevin.flow_mle_step(net, opt, zk, f_max_norm=100.0, fused=True)
+    assert l3.item() < l2.item() <= l1.item()

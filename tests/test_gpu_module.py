@@ -65,7 +65,7 @@ def _mle_backward(net, z2d, dev):
 
 
 @pytest.mark.parametrize("name", [n for n in golden_names() if "trained_s3" not in n])
-def test_flow_mle_call_site_param_grads(lsnf, gpu_device, name):
+def test_flow_mle_call_site_param_grads(lsnf, kernels, gpu_device, name):
     """Parameter gradients of the flow-MLE step vs the reference's (golden) for all 60 live tensors.
     A row that sits on a ReLU kink (oracle.relu_margin) has no well-defined fp32 gradient: if the fixture
     holds such rows, the strict comparison runs on the kink-free rows against the oracle (itself pinned to
@@ -158,7 +158,7 @@ def test_fused_helpers_match_module_path(lsnf, gpu_device):
     assert ((grad - g2).norm() / g2.norm()).item() <= 1e-6
 
 
-def test_params_and_z_grads_in_one_backward(lsnf, gpu_device):
+def test_params_and_z_grads_in_one_backward(lsnf, kernels, gpu_device):
     p, g = load_golden("c1_nz100_w64_B256")
     net, nz = make_net(lsnf, p, g, gpu_device)
     z = torch.from_numpy(g["z"]).to(gpu_device).clone().requires_grad_(True)
