@@ -63,6 +63,22 @@ __device__ __forceinline__ f32x16 small_gate16(f32x16 a, const f32x16& gate) {
 template <int KTL>
 struct SmallFrags { f32x4 w[KTL * 4]; };
 
+// a fetch in progress: pointer to this wave's slice + the registers it lands in.  The loads are issued by the
+// stage that runs meanwhile (SmallStage::run(..., fetch)), one or two after each group of 4 MFMAs: issued in one
+// burst at the start of a stage they hold the wave's MFMA chain back for the ~16 cycles per KiB the CU's vector
+// memory path needs (64 B/clk: 2000+ cycles per block, ~15 % of the kernel at batch 100).
+template <int KTL>
+struct SmallFetch {
+    static constexpr int N = KTL * 4;
+    const f32x4* g;
+    SmallFrags<KTL> f;
+    template <int I> __device__ __forceinline__ void issue() { f.w[I] = g[I * 64]; }
+    __device__ __forceinline__ void issue_all() {
+#pragma unroll
+        for (int i = 0; i < N; ++i) f.w[i] = g[i * 64];
+    }
+};
+
 // One GEMM stage out[nt] = init(nt) + W_nt^T in, NT output tiles, KT input tiles, spread over the 4 waves.
 // Outputs are written to LDS as NT*KS (partial) tiles, index nt*KS + ks; the caller's `in(kt)` functor returns
 // input tile kt in accumulator layout (it gathers / activates / gates whatever the producer left in LDS).
@@ -76,16 +92,56 @@ struct SmallStage {
     // issue the global loads of this wave's weight fragments (panels: n-tile major, KT k-tiles each)
     __device__ static __forceinline__ SmallFrags<KTL> fetch(const float* gpanels, int wave, int lane) {
         SmallFrags<KTL> f;
-        if (wave < UNITS) {
-            const int nt = wave / KS, ks = wave % KS;
-            const f32x4* g = reinterpret_cast<const f32x4*>(gpanels + ((size_t)nt * KT + ks * KTL) * LSNF_FRAG_FLOATS) + lane;
+        // NOT under `if (wave < UNITS)`: a load inside a branch makes every later s_waitcnt vmcnt conservative
+        // (the compiler must assume either path), which serialises each stage behind the fetch it has just
+        // issued for the next one.  Idle waves fetch unit 0's slice and never use it.
+        const int u = wave < UNITS ? wave : 0;
+        const int nt = u / KS, ks = u % KS;
+        const f32x4* g = reinterpret_cast<const f32x4*>(gpanels + ((size_t)nt * KT + ks * KTL) * LSNF_FRAG_FLOATS) + lane;
 #pragma unroll
-            for (int i = 0; i < KTL * 4; ++i) f.w[i] = g[i * 64];
-        } else {
-#pragma unroll
-            for (int i = 0; i < KTL * 4; ++i) f.w[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int i = 0; i < KTL * 4; ++i) f.w[i] = g[i * 64];
         return f;
+    }
+
+    // start a fetch of this stage's fragments that a running stage will issue (see SmallFetch)
+    __device__ static __forceinline__ SmallFetch<KTL> begin_fetch(const float* gpanels, int wave, int lane) {
+        SmallFetch<KTL> p;
+        const int u = wave < UNITS ? wave : 0;           // idle waves fetch unit 0's slice: no loads under a branch
+        const int nt = u / KS, ks = u % KS;
+        p.g = reinterpret_cast<const f32x4*>(gpanels + ((size_t)nt * KT + ks * KTL) * LSNF_FRAG_FLOATS) + lane;
+        return p;
+    }
+
+    // run this stage and, between its MFMA groups, issue the loads of `nf` (the fragments of a later stage)
+    template <class InFn, class InitFn, int NKTL>
+    __device__ static __forceinline__ void run(const SmallFrags<KTL>& fr, float* out_lds, int wave, int lane, InFn&& in,
+                                               InitFn&& init, SmallFetch<NKTL>& nf) {
+        if constexpr (UNITS < 4) {
+            if (wave >= UNITS) { nf.issue_all(); return; }   // wave-uniform; same number of loads on both paths
+        }
+        constexpr int G = KTL * 4, L = NKTL * 4, PER = (L + G - 1) / G;
+        const int nt = wave / KS, ks = wave % KS;
+        f32x16 acc = (ks == 0) ? init(nt) : lsnf_zero16();
+        f32x16 x;
+        lsnf_static_for<G>([&](auto gi) {
+            constexpr int k = gi / 4, g = gi % 4;
+            if constexpr (g == 0) {
+                if constexpr (std::is_invocable_v<InFn, int, int>) x = in(ks * KTL + k, k);
+                else x = in(ks * KTL + k);
+            }
+            const f32x4 w = fr.w[k * 4 + g];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], x[4 * g + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], x[4 * g + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], x[4 * g + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], x[4 * g + 3], acc, 0, 0, 0);
+            constexpr int L0 = gi * PER, L1 = (L0 + PER < L) ? L0 + PER : L;
+            if constexpr (L0 < L) {
+                lsnf_static_for<L1 - L0>([&](auto j) { nf.template issue<L0 + j>(); });
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);           // 4 MFMA, then
+                __builtin_amdgcn_sched_group_barrier(0x020, L1 - L0, 0);     // this group's VMEM reads
+            }
+        });
+        small_store_tile(out_lds + (size_t)(nt * KS + ks) * LSNF_TILE_FLOATS, acc, lane);
     }
 
     template <class InFn, class InitFn>

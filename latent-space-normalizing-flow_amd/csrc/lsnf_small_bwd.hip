@@ -87,9 +87,13 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(cons
     auto T = [&](int t) { return tiles + (size_t)t * LSNF_TILE_FLOATS; };
 
     const int last = a.depth - 1;
-    // first stage's weights in flight: R2 of the last block, or (SAVED) its B4
-    auto f2 = C::R2::fetch(a.fwd_panels + (size_t)last * C::FWD_BLOCK + (SAVED ? 0 : C::OFF_S2), SAVED ? 4 : wave, lane);
-    auto fb4 = C::B4::fetch(a.bwd_panels + (size_t)last * C::BWD_BLOCK + C::OFF_B4, SAVED ? wave : 4, lane);
+    // weights travel L2/HBM -> VGPR two stages ahead of their use, issued between the MFMA groups of the running
+    // stage (lsnf_small.h, SmallFetch).  In flight at loop entry: R2, R3 of the last block, or (SAVED) its B4, B3;
+    // the pair the variant does not use is dead code.
+    auto f2 = C::R2::fetch(a.fwd_panels + (size_t)last * C::FWD_BLOCK + C::OFF_S2, wave, lane);
+    auto f3 = C::R3::fetch(a.fwd_panels + (size_t)last * C::FWD_BLOCK + C::OFF_S3, wave, lane);
+    auto fb4 = C::B4::fetch(a.bwd_panels + (size_t)last * C::BWD_BLOCK + C::OFF_B4, wave, lane);
+    auto fb3 = C::B3::fetch(a.bwd_panels + (size_t)last * C::BWD_BLOCK + C::OFF_B3, wave, lane);
     // SAVED: this wave's slice of the stash, one block ahead: sigma tiles, h2 masks of its B3 slice, h1 masks
     const LsnfActLayout al = lsnf_act_layout(a.B, HT, WT);
     constexpr int K3 = C::B3::KTL;
@@ -152,20 +156,21 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(cons
 
         if constexpr (!SAVED) {
         // ---- R2: h1 = W1'^T v1 + c1 ----
-        auto f3 = C::R3::fetch(gf + C::OFF_S3, wave, lane);
-        C::R2::run(f2, H1, wave, lane, [&](int kt) { return tile(Y, kt); }, [&](int nt) { return lsnf_bias_init(cb + 32 * nt, h); });
+        auto p4 = C::R4::begin_fetch(gf + C::OFF_S4, wave, lane);
+        C::R2::run(f2, H1, wave, lane, [&](int kt) { return tile(Y, kt); }, [&](int nt) { return lsnf_bias_init(cb + 32 * nt, h); }, p4);
         __syncthreads();
         // ---- R3: h2 = W2'^T relu(h1) + c2 ----
-        auto f4 = C::R4::fetch(gf + C::OFF_S4, wave, lane);
+        auto pb4 = C::B4::begin_fetch(gb + C::OFF_B4, wave, lane);
         C::R3::run(f3, H2, wave, lane,
                    [&](int kt) { return small_gather_tile<C::R2::KS, true>(H1 + (size_t)kt * C::R2::KS * LSNF_TILE_FLOATS, lane); },
-                   [&](int nt) { return lsnf_bias_init(cb + 32 * (C::P2 + nt), h); });
+                   [&](int nt) { return lsnf_bias_init(cb + 32 * (C::P2 + nt), h); }, pb4);
         __syncthreads();
         // ---- R4: [t; p] ----
-        fb4 = C::B4::fetch(gb + C::OFF_B4, wave, lane);
-        C::R4::run(f4, TP, wave, lane,
+        auto pb3 = C::B3::begin_fetch(gb + C::OFF_B3, wave, lane);
+        C::R4::run(p4.f, TP, wave, lane,
                    [&](int kt) { return small_gather_tile<C::R3::KS, true>(H2 + (size_t)kt * C::R3::KS * LSNF_TILE_FLOATS, lane); },
-                   [&](int nt) { return lsnf_bias_init(cb + 32 * (C::P2 + C::P3 + nt), h); });
+                   [&](int nt) { return lsnf_bias_init(cb + 32 * (C::P2 + C::P3 + nt), h); }, pb3);
+        fb4 = pb4.f; fb3 = pb3.f;
         __syncthreads();
         // ---- CB: coupling backward on waves 0..HT-1 ----
         if (wave < HT) {
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(cons
         __syncthreads();
         }   // !SAVED
         // ---- B4: g_h2 = [W3s W3p][g_t; g_p] ----
-        auto fb3 = C::B3::fetch(gb + C::OFF_B3, wave, lane);
+        auto pb2 = C::B2::begin_fetch(gb + C::OFF_B2, wave, lane);
         if constexpr (SAVED) {
             // operand tile kt (< HT: g_t_kt, else g_p_{kt-HT}) built on the fly from the stashed sigma; the wave that
             // owns output tile 0 also leaves g_v2 = g_t in GV for B1.  kt % HT == k % HT for every split of B4.
@@ -212,13 +217,13 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(cons
                            }
                            return o;
                        },
-                       [&](int) { return lsnf_zero16(); });
+                       [&](int) { return lsnf_zero16(); }, pb2);
         } else {
-            C::B4::run(fb4, GH2, wave, lane, [&](int kt) { return tile(GTP, kt); }, [&](int) { return lsnf_zero16(); });
+            C::B4::run(fb4, GH2, wave, lane, [&](int kt) { return tile(GTP, kt); }, [&](int) { return lsnf_zero16(); }, pb2);
         }
         __syncthreads();
         // ---- B3: g_h1 = W2' (g_h2 gated by h2 > 0) ----
-        auto fb2 = C::B2::fetch(gb + C::OFF_B2, wave, lane);
+        auto pb1 = C::B1::begin_fetch(gb + C::OFF_B1, wave, lane);
         C::B3::run(fb3, GH1, wave, lane,
                    [&](int kt, int k) {
                        const f32x16 gh = small_gather_tile<C::B4::KS, false>(GH2 + (size_t)kt * C::B4::KS * LSNF_TILE_FLOATS, lane);
@@ -235,15 +240,16 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(cons
                            return ga;
                        }
                    },
-                   [&](int) { return lsnf_zero16(); });
+                   [&](int) { return lsnf_zero16(); }, pb1);
         __syncthreads();
         // ---- B2: g_v1 = g_v1(direct) + W1' (g_h1 gated by h1 > 0) -> GV[0..HT) ----
-        auto fb1 = C::B1::fetch(gb + C::OFF_B1, wave, lane);
+        const int nb = blk > 0 ? blk - 1 : 0;      // block 0 re-fetches its own panels: no loads under a branch
         // next block's output tile: global load issued here, parked in registers until Y is free
-        f32x16 ynext = lsnf_zero16();
-        if (blk > 0 && wave < NZT)
-            ynext = lsnf_load_tile<HT>(wave, a.z_saved + ((size_t)(blk - 1) * a.B + row) * a.nz, a.half, h, vec4);
-        C::B2::run(fb2, GV, wave, lane,
+        // (unconditional for the same reason: idle waves / block 0 load a valid tile and drop it)
+        const float* ysrc = blk > 0 ? a.z_saved + ((size_t)(blk - 1) * a.B + row) * a.nz : a.z_out + row * (long)a.nz;
+        const f32x16 ynext = lsnf_load_tile<HT>(wave < NZT ? wave : 0, ysrc, a.half, h, vec4);
+        auto run_b2 = [&](auto& pn) {
+        C::B2::run(pb2.f, GV, wave, lane,
                    [&](int kt, int k) {
                        const f32x16 gh = small_gather_tile<C::B3::KS, false>(GH1 + (size_t)kt * C::B3::KS * LSNF_TILE_FLOATS, lane);
                        if constexpr (SAVED) return lsnf_apply_mask16(gh, mk1[k]);
@@ -259,14 +265,15 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(cons
                            return ga;
                        }
                    },
-                   [&](int nt) { return tile(GX, nt); });
+                   [&](int nt) { return tile(GX, nt); }, pn);
+        };
+        if constexpr (SAVED) { auto pn = C::B4::begin_fetch(a.bwd_panels + (size_t)nb * C::BWD_BLOCK + C::OFF_B4, wave, lane); run_b2(pn); fb4 = pn.f; }
+        else { auto pn = C::R2::begin_fetch(a.fwd_panels + (size_t)nb * C::FWD_BLOCK + C::OFF_S2, wave, lane); run_b2(pn); f2 = pn.f; }
         __syncthreads();
         // ---- B1: g_x = Wa [g_v1; g_v2] -> GXn ----
-        if (blk > 0) {
-            if constexpr (SAVED) { fb4 = C::B4::fetch(a.bwd_panels + (size_t)(blk - 1) * C::BWD_BLOCK + C::OFF_B4, wave, lane); fetch_act(blk - 1); }
-            else f2 = C::R2::fetch(a.fwd_panels + (size_t)(blk - 1) * C::FWD_BLOCK + C::OFF_S2, wave, lane);
-        }
-        C::B1::run(fb1, GXn, wave, lane,
+        if constexpr (SAVED) fetch_act(nb);
+        auto run_b1 = [&](auto& pn) {
+        C::B1::run(pb1.f, GXn, wave, lane,
                    [&](int kt) {
                        const f32x16 gvt = tile(GV, kt);
                        if constexpr (DUMP) {
@@ -274,7 +281,10 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(cons
                        }
                        return gvt;
                    },
-                   [&](int) { return lsnf_zero16(); });
+                   [&](int) { return lsnf_zero16(); }, pn);
+        };
+        if constexpr (SAVED) { auto pn = C::B3::begin_fetch(a.bwd_panels + (size_t)nb * C::BWD_BLOCK + C::OFF_B3, wave, lane); run_b1(pn); fb3 = pn.f; }
+        else { auto pn = C::R3::begin_fetch(a.fwd_panels + (size_t)nb * C::FWD_BLOCK + C::OFF_S3, wave, lane); run_b1(pn); f3 = pn.f; }
         if (blk > 0 && wave < NZT) small_store_tile(Y + (size_t)wave * LSNF_TILE_FLOATS, ynext, lane);   // Y's readers are done
         __syncthreads();
     }

@@ -32,7 +32,18 @@ struct SmallFwdArgs {
     float* act_saved;      // NULL or the activation stash (already offset to first_block), lsnf_layout.h LsnfActLayout
     double* stats;
     int B, nz, half, n_blocks, vec4;
+    unsigned long long* stamps;        // LSNF_STAMPS diagnostic build only: [grid][4 waves][64] shader-clock stamps
 };
+
+#ifdef LSNF_STAMPS
+#define SMALL_STAMP(i)                                                                                  \
+    do { __builtin_amdgcn_sched_barrier(0);                                                             \
+         unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+         __builtin_amdgcn_sched_barrier(0);                                                             \
+         if (a.stamps && lane == 0) a.stamps[(((size_t)blockIdx.x * 4 + wave) & 2047) * 64 + (i)] = t_; } while (0)
+#else
+#define SMALL_STAMP(i) do {} while (0)
+#endif
 
 template <class C>
 __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_fwd_kernel(const SmallFwdArgs a) {
@@ -46,7 +57,11 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_fwd_kernel(cons
     const int lane = tid & 63, m = lane & 31, h = lane >> 5;
     const int vec4 = a.vec4;
 
-    auto f1 = C::S1::fetch(a.panels, wave, lane);                   // first stage's weights in flight
+    SMALL_STAMP(0);
+    // weights travel L2/HBM -> VGPR TWO stages ahead of their use (a fetch costs ~3000 cycles when the line comes
+    // from HBM -- the L2 starts every launch cold -- and a stage lasts 1000..4000)
+    auto f1 = C::S1::fetch(a.panels, wave, lane);
+    auto f2 = C::S2::fetch(a.panels + C::OFF_S2, wave, lane);
     for (int i = tid; i < a.n_blocks * C::CONST_FLOATS; i += LSNF_WG_THREADS) cst[i] = a.consts[i];
 
     const long sample = (long)blockIdx.x * LSNF_SMALL_SAMPLES + m;
@@ -58,6 +73,7 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_fwd_kernel(cons
     if (wave == 0) ell = a.objective ? a.objective[row] : 0.0f;
     const LsnfActLayout al = lsnf_act_layout(a.B, HT, WT);
     __syncthreads();
+    SMALL_STAMP(1);
 
     for (int blk = 0; blk < a.n_blocks; ++blk) {
         const float* cb = cst + blk * C::CONST_FLOATS;
@@ -72,38 +88,51 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_fwd_kernel(cons
         float* act = a.act_saved ? a.act_saved + (size_t)blk * al.per_block + (size_t)blockIdx.x * al.per_tile : nullptr;
 
         // ---- S1 (actnorm + 1x1 conv, model.py:244,268,187); weights of S2 fetched meanwhile ----
-        auto f2 = C::S2::fetch(gblk + C::OFF_S2, wave, lane);
+        auto p3 = C::S3::begin_fetch(gblk + C::OFF_S3, wave, lane);
         C::S1::run(f1, V, wave, lane, [&](int kt) { return small_load_tile(X + (size_t)kt * LSNF_TILE_FLOATS, lane); },
-                   [&](int nt) { return lsnf_bias_init(cb + 32 * nt, h); });
+                   [&](int nt) { return lsnf_bias_init(cb + 32 * nt, h); }, p3);
         if (wave == 0) {   // logdet += sum(3 logs) ; += log|det W|   (model.py:273-276, 182, 189)
             ell = ell + cb[32 * C::NP + 0];
             ell = ell + cb[32 * C::NP + 1];
         }
+        SMALL_STAMP(2 + 10 * blk + 0);
         __syncthreads();
+        SMALL_STAMP(2 + 10 * blk + 1);
         // ---- S2 (model.py:326-328) ----
-        auto f3 = C::S3::fetch(gblk + C::OFF_S3, wave, lane);
+        auto p4 = C::S4::begin_fetch(gblk + C::OFF_S4, wave, lane);
         C::S2::run(f2, H1, wave, lane,
                    [&](int kt) { return small_gather_tile<C::S1::KS, false>(V + (size_t)kt * C::S1::KS * LSNF_TILE_FLOATS, lane); },
-                   [&](int nt) { return lsnf_bias_init(cb + 32 * (C::P1 + nt), h); });
+                   [&](int nt) { return lsnf_bias_init(cb + 32 * (C::P1 + nt), h); }, p4);
+        SMALL_STAMP(2 + 10 * blk + 2);
         __syncthreads();
+        SMALL_STAMP(2 + 10 * blk + 3);
         // ---- S3 ----
-        auto f4 = C::S4::fetch(gblk + C::OFF_S4, wave, lane);
+        // unconditional (the last block re-fetches its own panels): a fetch under `if (more)` would make the
+        // s_waitcnt of this stage conservative, see SmallStage::fetch
+        const float* gnext = more ? gblk + C::BLOCK_FLOATS : gblk;
+        auto p1 = C::S1::begin_fetch(gnext, wave, lane);
         if (act && wave < WT)   // relu mask of h1 tile `wave` for the backward (model.py:307)
             *lsnf_act_mask_ptr(act, al.mask_off, wave, lane) =
                 lsnf_posmask16(small_gather_tile<C::S2::KS, false>(H1 + (size_t)wave * C::S2::KS * LSNF_TILE_FLOATS, lane));
-        C::S3::run(f3, H2, wave, lane,
+        C::S3::run(p3.f, H2, wave, lane,
                    [&](int kt) { return small_gather_tile<C::S2::KS, true>(H1 + (size_t)kt * C::S2::KS * LSNF_TILE_FLOATS, lane); },
-                   [&](int nt) { return lsnf_bias_init(cb + 32 * (C::P1 + C::P2 + nt), h); });
+                   [&](int nt) { return lsnf_bias_init(cb + 32 * (C::P1 + C::P2 + nt), h); }, p1);
+        f1 = p1.f;
+        SMALL_STAMP(2 + 10 * blk + 4);
         __syncthreads();
+        SMALL_STAMP(2 + 10 * blk + 5);
         // ---- S4 (fc_zeros, shift / pre-sigmoid de-interleaved, model.py:347-349,411-413) ----
-        if (more) f1 = C::S1::fetch(gblk + C::BLOCK_FLOATS, wave, lane);
+        auto p2 = C::S2::begin_fetch(gnext + C::OFF_S2, wave, lane);
         if (act && wave < WT)
             *lsnf_act_mask_ptr(act, al.mask_off, WT + wave, lane) =
                 lsnf_posmask16(small_gather_tile<C::S3::KS, false>(H2 + (size_t)wave * C::S3::KS * LSNF_TILE_FLOATS, lane));
-        C::S4::run(f4, TP, wave, lane,
+        C::S4::run(p4.f, TP, wave, lane,
                    [&](int kt) { return small_gather_tile<C::S3::KS, true>(H2 + (size_t)kt * C::S3::KS * LSNF_TILE_FLOATS, lane); },
-                   [&](int nt) { return lsnf_bias_init(cb + 32 * (C::P1 + C::P2 + C::P3 + nt), h); });
+                   [&](int nt) { return lsnf_bias_init(cb + 32 * (C::P1 + C::P2 + C::P3 + nt), h); }, p2);
+        f2 = p2.f;
+        SMALL_STAMP(2 + 10 * blk + 6);
         __syncthreads();
+        SMALL_STAMP(2 + 10 * blk + 7);
         // ---- coupling (model.py:414-418): waves 0..HT-1 produce y2 tiles + log-scale partials,
         //      waves HT..2HT-1 forward the v1 tiles (concat, model.py:422) ----
         if (wave < HT) {
@@ -129,7 +158,9 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_fwd_kernel(cons
             small_store_tile(Xn + (size_t)j * LSNF_TILE_FLOATS,
                              small_gather_tile<C::S1::KS, false>(V + (size_t)j * C::S1::KS * LSNF_TILE_FLOATS, lane), lane);
         }
+        SMALL_STAMP(2 + 10 * blk + 8);
         __syncthreads();
+        SMALL_STAMP(2 + 10 * blk + 9);
         if (wave == 0) {              // logdet += sum_j log(scale_j)
             float ls = 0.0f;
 #pragma unroll
@@ -170,6 +201,7 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_fwd_kernel(cons
             if (lane == 0) lsnf_publish_stats(a.stats, dl, dd, a.B);
         }
     }
+    SMALL_STAMP(60);
 }
 
 template <class C>
@@ -194,6 +226,12 @@ hipError_t lsnf_launch_small_forward(const LsnfGeo& g, const float* plan, int fi
     a.panels = plan + g.off_fwd_panels + (size_t)first_block * g.fwd_block_floats;
     a.z_in = z_in; a.objective = objective; a.z_out = z_out; a.logdet_out = logdet_out; a.ll_out = ll_out;
     a.act_saved = act_saved ? act_saved + (size_t)first_block * lsnf_act_layout(B, g.HT, g.WT).per_block : nullptr;
+    a.stamps = nullptr;
+#ifdef LSNF_STAMPS
+    { extern unsigned long long* g_lsnf_stamps;
+      if (!g_lsnf_stamps) { if (hipMalloc(&g_lsnf_stamps, sizeof(unsigned long long) * 64 * 4 * 4096) != hipSuccess) g_lsnf_stamps = nullptr; }
+      a.stamps = g_lsnf_stamps; }
+#endif
     a.z_saved = z_saved; a.stats = stats; a.B = B; a.nz = g.nz; a.half = g.half; a.n_blocks = n_blocks; a.vec4 = vec4;
     if (g.HT == 1 && g.WT == 1) return launch_small_fwd<SmallFwdCfg<1, 1>>(a, stream);
     if (g.HT == 2 && g.WT == 2) return launch_small_fwd<SmallFwdCfg<2, 2>>(a, stream);

@@ -47,7 +47,9 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_rev_kernel(cons
     auto T = [&](int t) { return tiles + (size_t)t * LSNF_TILE_FLOATS; };
 
     const int last = a.depth - 1;
+    // weights two stages ahead, issued between the running stage's MFMA groups (lsnf_small.h, SmallFetch)
     auto f2 = C::R2::fetch(a.fwd_panels + (size_t)last * C::FWD_BLOCK + C::OFF_S2, wave, lane);
+    auto f3 = C::R3::fetch(a.fwd_panels + (size_t)last * C::FWD_BLOCK + C::OFF_S3, wave, lane);
     for (int i = tid; i < a.depth * C::CONST_PER_BLOCK; i += LSNF_WG_THREADS) {
         const int blk = i / C::CONST_PER_BLOCK, r = i % C::CONST_PER_BLOCK;
         cst[i] = r < C::FWD_CONST ? a.fwd_consts[blk * C::FWD_CONST + r] : a.inv_consts[blk * C::INV_CONST + (r - C::FWD_CONST)];
@@ -71,19 +73,21 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_rev_kernel(cons
         float* H1 = T(C::T_H1); float* H2 = T(C::T_H2); float* TP = T(C::T_TP); float* U = T(C::T_U);
         auto tile = [&](const float* base, int t) { return small_load_tile(base + (size_t)t * LSNF_TILE_FLOATS, lane); };
 
-        auto f3 = C::R3::fetch(gf + C::OFF_S3, wave, lane);
+        auto p4 = C::R4::begin_fetch(gf + C::OFF_S4, wave, lane);
         C::R2::run(f2, H1, wave, lane, [&](int kt) { return tile(X, kt); },
-                   [&](int nt) { return lsnf_bias_init(cb + 32 * (C::P1 + nt), h); });
+                   [&](int nt) { return lsnf_bias_init(cb + 32 * (C::P1 + nt), h); }, p4);
         __syncthreads();
-        auto f4 = C::R4::fetch(gf + C::OFF_S4, wave, lane);
+        auto pi = C::I1::begin_fetch(gi, wave, lane);
         C::R3::run(f3, H2, wave, lane,
                    [&](int kt) { return small_gather_tile<C::R2::KS, true>(H1 + (size_t)kt * C::R2::KS * LSNF_TILE_FLOATS, lane); },
-                   [&](int nt) { return lsnf_bias_init(cb + 32 * (C::P1 + C::P2 + nt), h); });
+                   [&](int nt) { return lsnf_bias_init(cb + 32 * (C::P1 + C::P2 + nt), h); }, pi);
         __syncthreads();
-        auto fi = C::I1::fetch(gi, wave, lane);
-        C::R4::run(f4, TP, wave, lane,
+        const float* gfn = a.fwd_panels + (size_t)(blk > 0 ? blk - 1 : 0) * C::FWD_BLOCK;   // block 0 re-fetches its own panels
+        auto p2 = C::R2::begin_fetch(gfn + C::OFF_S2, wave, lane);
+        C::R4::run(p4.f, TP, wave, lane,
                    [&](int kt) { return small_gather_tile<C::R3::KS, true>(H2 + (size_t)kt * C::R3::KS * LSNF_TILE_FLOATS, lane); },
-                   [&](int nt) { return lsnf_bias_init(cb + 32 * (C::P1 + C::P2 + C::P3 + nt), h); });
+                   [&](int nt) { return lsnf_bias_init(cb + 32 * (C::P1 + C::P2 + C::P3 + nt), h); }, p2);
+        f2 = p2.f;
         __syncthreads();
         // inverse coupling on waves 0..HT-1; waves HT..2HT-1 forward z1
         if (wave < HT) {
@@ -114,8 +118,9 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_rev_kernel(cons
             obj = obj - cb[32 * C::NP + 1];   // logdet - log|det W|       (model.py:196)
             obj = obj - cb[32 * C::NP + 0];   // logdet - sum(3 logs)      (model.py:273-276, reverse)
         }
-        if (blk > 0) f2 = C::R2::fetch(a.fwd_panels + (size_t)(blk - 1) * C::FWD_BLOCK + C::OFF_S2, wave, lane);
-        C::I1::run(fi, Xn, wave, lane, [&](int kt) { return tile(U, kt); }, [&](int nt) { return lsnf_bias_init(ci + 32 * nt, h); });
+        auto p3 = C::R3::begin_fetch(gfn + C::OFF_S3, wave, lane);
+        C::I1::run(pi.f, Xn, wave, lane, [&](int kt) { return tile(U, kt); }, [&](int nt) { return lsnf_bias_init(ci + 32 * nt, h); }, p3);
+        f3 = p3.f;
         __syncthreads();
     }
     float* Xf = T(C::T_X + (1 & 1) * NZT);      // block 0 wrote X[(0+1)&1]
