@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LSNF_ABI_VERSION 2
+#define LSNF_ABI_VERSION 3
 
 #define LSNF_OK 0
 #define LSNF_E_ARG (-1)       /* bad argument (NULL pointer, size out of range, misaligned) */
@@ -141,11 +141,24 @@ int lsnf_backward_z(const float* plan, int nz, int width, int depth, int couplin
  *   z_cur  (B,nz) current latents (the z that lsnf_forward was run on); z_out / z_saved / act_saved
  *          (act_saved may be NULL) from that forward
  *   grad_g (B,nz) or NULL (= 0): the generator's gradient z_grad_g (train.py:314)
- *   noise  (B,nz) or NULL (= no noise, as the test-time sampler train.py:624-625): N(0,1) draws
+ *   noise  (B,nz) or NULL: N(0,1) draws supplied by the caller (train.py:326 `randn_like`)
+ *   rng    NULL, or (only when noise is NULL) the in-kernel generator below; both NULL = no noise, as the
+ *          test-time sampler (train.py:624-625)
  *   z_new  (B,nz), may alias z_cur (in-place update);  gf_norm, gg_norm: (B) or NULL. */
+typedef struct LsnfRng {
+    /* Counter-based N(0,1) noise made inside the update kernel: Philox4x32-10 + Box-Muller, a pure function of
+     * (seed, offset, global row, column) -- the same draw whatever the batch size, kernel family or sharding of
+     * the rows over GPUs (exact definition: csrc/lsnf_device.h lsnf_noise_tile, restated in
+     * oracle/philox_oracle.py).  Use a new `offset` for every Langevin step. */
+    unsigned long long seed;
+    unsigned long long offset;
+    const unsigned long long* offset_dev;   /* NULL, or device counter added to offset (captured graphs) */
+    long long row0;                         /* global index of this call's row 0 (sharded chains); usually 0 */
+} LsnfRng;
+
 int lsnf_langevin_step(const float* plan, int nz, int width, int depth, int coupling, int B,
                        const float* z_cur, const float* z_out, const float* z_saved, const float* act_saved,
-                       const float* grad_g, const float* noise, float step_size,
+                       const float* grad_g, const float* noise, const LsnfRng* rng, float step_size,
                        float* z_new, float* gf_norm, float* gg_norm, void* stream);
 
 /* ---- backward w.r.t. the parameters: replaces `loss_f.backward()` (train.py:406-411) --------

@@ -13,7 +13,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LSNF_LIB_PATH") or os.path.join(_HERE, "liblsnf_flow.so")
 
 LSNF_PARAMS_PER_BLOCK = 12
-ABI_VERSION = 2
+ABI_VERSION = 3
+
+class LsnfRng(ctypes.Structure):
+    """include/lsnf_flow.h `LsnfRng`: in-kernel Philox noise of lsnf_langevin_step."""
+    _fields_ = [("seed", ctypes.c_uint64), ("offset", ctypes.c_uint64), ("offset_dev", c_void_p), ("row0", ctypes.c_int64)]
+
 
 # name -> (restype, argtypes); mirrors include/lsnf_flow.h one to one
 _SIGNATURES = {
@@ -32,7 +37,7 @@ _SIGNATURES = {
     "lsnf_backward_z": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
     "lsnf_langevin_step": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(LsnfRng), c_float,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
     "lsnf_backward_params_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "lsnf_backward_params": (c_int, [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),

@@ -215,7 +215,7 @@ int lsnf_backward_z(const float* plan, int nz, int width, int depth, int couplin
 
 int lsnf_langevin_step(const float* plan, int nz, int width, int depth, int coupling, int B, const float* z_cur,
                        const float* z_out, const float* z_saved, const float* act_saved, const float* grad_g,
-                       const float* noise, float step_size, float* z_new, float* gf_norm, float* gg_norm, void* stream) {
+                       const float* noise, const LsnfRng* rng, float step_size, float* z_new, float* gf_norm, float* gg_norm, void* stream) {
     LsnfGeo g;
     if (int rc = geo_or_fail(&g, nz, width, depth, coupling)) return rc;
     if (B < 0 || B > (1 << 28)) return fail(LSNF_E_ARG, "lsnf_langevin_step: B=%d out of range", B);
@@ -227,7 +227,13 @@ int lsnf_langevin_step(const float* plan, int nz, int width, int depth, int coup
         return fail(LSNF_E_ARG, "lsnf_langevin_step: tensors must be 4-byte aligned");
     const int vec4 = row_vector_width(g, {z_out, z_saved, z_cur, grad_g, noise, z_new});
     if (act_saved && !aligned16(act_saved)) return fail(LSNF_E_ARG, "lsnf_langevin_step: act_saved must be 16-byte aligned");
-    LsnfLangevinArgs lv = {z_cur, grad_g, noise, z_new, gf_norm, gg_norm, step_size};
+    if (noise && rng) return fail(LSNF_E_ARG, "lsnf_langevin_step: pass either a noise tensor or an rng, not both");
+    if (rng && rng->offset_dev && (reinterpret_cast<uintptr_t>(rng->offset_dev) & 7u))
+        return fail(LSNF_E_ARG, "lsnf_langevin_step: rng->offset_dev must be 8-byte aligned");
+    if (rng && rng->row0 < 0) return fail(LSNF_E_ARG, "lsnf_langevin_step: rng->row0 must be >= 0");
+    LsnfLangevinArgs lv = {z_cur, grad_g, noise, z_new, gf_norm, gg_norm, step_size,
+                           rng ? LsnfRngArgs{rng->seed, rng->offset, rng->offset_dev, rng->row0, 1}
+                               : LsnfRngArgs{0ull, 0ull, nullptr, 0ll, 0}};
     hipError_t e = (B <= small_batch_max())
         ? lsnf_launch_small_backward_z(g, plan, B, z_out, z_saved, nullptr, nullptr, /*ll_mode=*/1, /*ll_scale=*/-1.0f,
                                        nullptr, vec4, (hipStream_t)stream, &lv, act_saved)

@@ -29,6 +29,7 @@ struct BwdArgs {
     // fused Langevin update (train.py:324-329): z_new = z_cur - 0.5 s^2 (grad_g + g_z_in) + s * noise
     const float* z_cur; const float* grad_g; const float* noise; float* z_new; float* gf_norm; float* gg_norm;
     float step;
+    LsnfRngArgs rng;        // Langevin update: in-kernel noise when `noise` is NULL and rng.enabled
     float ll_scale;
     int ll_mode, B, nz, half, width, depth, vec4;
 };
@@ -245,6 +246,11 @@ __global__ __launch_bounds__(64 * NW, ((C::WT >= 4 && !SAVED) ? 1 : 2)) void lsn
     if (a.z_new) {   // wave-uniform: fused Langevin update, tile by tile (keeps the register footprint flat)
         const float coef = 0.5f * a.step * a.step;
         float gf2 = 0.0f, gg2 = 0.0f;
+        LsnfRngState rs = {0u, 0u, 0u, 0u, 0};
+        if (!a.noise && a.rng.enabled) {
+            const unsigned long long off = a.rng.offset + (a.rng.offset_dev ? *a.rng.offset_dev : 0ull);
+            rs = {(unsigned)a.rng.seed, (unsigned)(a.rng.seed >> 32), (unsigned)off, (unsigned)(off >> 32), 1};
+        }
         const float* zr = a.z_cur + row * (long)a.nz;
         float* zo = a.z_new + row * (long)a.nz;
 #pragma unroll
@@ -265,6 +271,10 @@ __global__ __launch_bounds__(64 * NW, ((C::WT >= 4 && !SAVED) ? 1 : 2)) void lsn
                 const f32x16 nv = lsnf_load_tile<HT>(t, a.noise + row * (long)a.nz, a.half, h, vec4);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) zn[r] = zn[r] + a.step * nv[r];                    // train.py:326
+            } else if (rs.on) {
+                const f32x16 nv = lsnf_noise_tile<HT>(t, (unsigned long long)(a.rng.row0 + sample), a.half, h, rs);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zn[r] = zn[r] + a.step * nv[r];
             }
             if (live) lsnf_store_tile<HT>(t, zn, zo, a.half, h, vec4);
         }
@@ -303,10 +313,11 @@ hipError_t lsnf_launch_backward_z(const LsnfGeo& g, const float* plan, int B, co
                                   const LsnfLangevinArgs* lv, const float* act_saved) {
     BwdArgs a;
     a.act_saved = dump ? nullptr : act_saved;
+    a.rng = LsnfRngArgs{0ull, 0ull, nullptr, 0ll, 0};
     a.dump = dump; a.gl_total = gl_total; a.width = g.width;
     a.z_cur = nullptr; a.grad_g = nullptr; a.noise = nullptr; a.z_new = nullptr; a.gf_norm = nullptr; a.gg_norm = nullptr; a.step = 0.f;
     if (lv) { a.z_cur = lv->z_cur; a.grad_g = lv->grad_g; a.noise = lv->noise; a.z_new = lv->z_new; a.gf_norm = lv->gf_norm;
-              a.gg_norm = lv->gg_norm; a.step = lv->step; }
+              a.gg_norm = lv->gg_norm; a.step = lv->step; a.rng = lv->rng; }
     a.fwd_consts = plan + g.off_fwd_const; a.fwd_panels = plan + g.off_fwd_panels; a.bwd_panels = plan + g.off_bwd_panels;
     a.z_out = z_out; a.z_saved = z_saved; a.g_z1 = g_z1; a.g_logdet = g_logdet; a.g_z_in = g_z_in;
     a.ll_scale = ll_scale; a.ll_mode = ll_mode; a.B = B; a.nz = g.nz; a.half = g.half; a.depth = g.depth; a.vec4 = vec4;

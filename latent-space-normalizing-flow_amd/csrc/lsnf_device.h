@@ -392,6 +392,47 @@ __device__ __forceinline__ const unsigned* lsnf_act_mask_ptr(const float* tile_b
     return reinterpret_cast<const unsigned*>(tile_base + mask_off) + idx * 64 + lane;
 }
 
+// ---- counter-based Gaussian noise for the fused Langevin update (train.py:326, `s * randn_like(z)`) ----
+// noise(row, col), col = hh*half + f (hh: which half of the latent, f: feature within it), is normal number (f & 3)
+// of the four made from Philox4x32-10 with
+//   counter = ( (hh << 16) | (f >> 2),  row & 0xffffffff,  offset & 0xffffffff,  (offset >> 32) ^ (row >> 32) )
+//   key     = ( seed & 0xffffffff, seed >> 32 ),            row = global row index (row0 + local row)
+// Box-Muller on (x0,x1) -> normals 0,1 and (x2,x3) -> normals 2,3, u = ((x >> 8) + 0.5) * 2^-24.
+// A pure function of (seed, offset, row, col): independent of the kernel family, of the batch sharding and of B.
+__device__ __forceinline__ void lsnf_philox4x32_10(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ void lsnf_box_muller(unsigned xa, unsigned xb, float& n0, float& n1) {
+    const float u1 = ((float)(xa >> 8) + 0.5f) * 5.9604644775390625e-08f;      // (0, 1)
+    const float u2 = ((float)(xb >> 8) + 0.5f) * 5.9604644775390625e-08f;
+    const float r = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1), v_log_f32 = log2
+    n0 = r * __builtin_amdgcn_cosf(u2);                                         // v_cos/v_sin take revolutions
+    n1 = r * __builtin_amdgcn_sinf(u2);
+}
+struct LsnfRngState { unsigned k0, k1, c2, c3hi; int on; };
+template <int HT>
+__device__ __forceinline__ f32x16 lsnf_noise_tile(int t, unsigned long long grow, int half, int h, const LsnfRngState& st) {
+    f32x16 x;
+    const int hh = t / HT, tt = t % HT;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int f0 = 32 * tt + 8 * g + 4 * h;
+        unsigned c0 = ((unsigned)hh << 16) | (unsigned)(f0 >> 2), c1 = (unsigned)grow, c2 = st.c2, c3 = st.c3hi ^ (unsigned)(grow >> 32);
+        lsnf_philox4x32_10(c0, c1, c2, c3, st.k0, st.k1);
+        float n0, n1, n2, n3;
+        lsnf_box_muller(c0, c1, n0, n1);
+        lsnf_box_muller(c2, c3, n2, n3);
+        x[4 * g + 0] = n0; x[4 * g + 1] = n1; x[4 * g + 2] = n2; x[4 * g + 3] = n3;
+    }
+    return x;
+}
+
 // bit r of the result = (a[r] > 0): relu mask of one tile, for the backward pass
 __device__ __forceinline__ unsigned lsnf_posmask16(const f32x16& a) {
     unsigned m = 0;

@@ -42,9 +42,18 @@ struct LsnfGeo {
 };
 
 // optional tail of the backward kernel: the Langevin update of train.py:324-329
+// in-kernel noise of the Langevin update: counter-based (Philox4x32-10), a pure function of
+// (seed, offset, global row, column) -- see lsnf_device.h lsnf_noise_tile and oracle/philox_oracle.py
+struct LsnfRngArgs {
+    unsigned long long seed, offset;
+    const unsigned long long* offset_dev;   // NULL, or a device counter added to `offset` (for captured graphs)
+    long long row0;                         // global index of this call's first row (sharded chains)
+    int enabled;
+};
 struct LsnfLangevinArgs {
     const float* z_cur; const float* grad_g; const float* noise;
     float* z_new; float* gf_norm; float* gg_norm; float step;
+    LsnfRngArgs rng;
 };
 
 static inline int lsnf_ceil_div(int a, int b) { return (a + b - 1) / b; }

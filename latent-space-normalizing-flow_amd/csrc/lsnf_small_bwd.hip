@@ -52,6 +52,7 @@ struct SmallBwdArgs {
     float* dump; float* gl_total;      // DUMP variant only
     const float* z_cur; const float* grad_g; const float* noise; float* z_new; float* gf_norm; float* gg_norm;
     float step, ll_scale;
+    LsnfRngArgs rng;                   // Langevin update: in-kernel noise when `noise` is NULL and rng.enabled
     int ll_mode, B, nz, half, width, depth, vec4;
 };
 
@@ -313,6 +314,12 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_bwd_kernel(cons
                 const f32x16 nv = lsnf_load_tile<HT>(wave, a.noise + row * (long)a.nz, a.half, h, vec4);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) zn[r] = zn[r] + a.step * nv[r];
+            } else if (a.rng.enabled) {
+                const unsigned long long off = a.rng.offset + (a.rng.offset_dev ? *a.rng.offset_dev : 0ull);
+                const LsnfRngState rs = {(unsigned)a.rng.seed, (unsigned)(a.rng.seed >> 32), (unsigned)off, (unsigned)(off >> 32), 1};
+                const f32x16 nv = lsnf_noise_tile<HT>(wave, (unsigned long long)(a.rng.row0 + sample), a.half, h, rs);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zn[r] = zn[r] + a.step * nv[r];
             }
             if (live) lsnf_store_tile<HT>(wave, zn, a.z_new + sample * (long)a.nz, a.half, h, vec4);
         }
@@ -361,9 +368,10 @@ hipError_t lsnf_launch_small_backward_z(const LsnfGeo& g, const float* plan, int
     a.dump = dump; a.gl_total = gl_total; a.width = g.width;
     a.fwd_consts = plan + g.off_fwd_const; a.fwd_panels = plan + g.off_fwd_panels; a.bwd_panels = plan + g.off_bwd_panels;
     a.z_out = z_out; a.z_saved = z_saved; a.g_z1 = g_z1; a.g_logdet = g_logdet; a.g_z_in = g_z_in;
+    a.rng = LsnfRngArgs{0ull, 0ull, nullptr, 0ll, 0};
     a.z_cur = nullptr; a.grad_g = nullptr; a.noise = nullptr; a.z_new = nullptr; a.gf_norm = nullptr; a.gg_norm = nullptr; a.step = 0.f;
     if (lv) { a.z_cur = lv->z_cur; a.grad_g = lv->grad_g; a.noise = lv->noise; a.z_new = lv->z_new; a.gf_norm = lv->gf_norm;
-              a.gg_norm = lv->gg_norm; a.step = lv->step; }
+              a.gg_norm = lv->gg_norm; a.step = lv->step; a.rng = lv->rng; }
     a.ll_scale = ll_scale; a.ll_mode = ll_mode; a.B = B; a.nz = g.nz; a.half = g.half; a.depth = g.depth; a.vec4 = vec4;
     if (g.HT == 1 && g.WT == 1) return launch_small_bwd<SmallBwdCfg<1, 1>>(a, stream);
     if (g.HT == 2 && g.WT == 2) return launch_small_bwd<SmallBwdCfg<2, 2>>(a, stream);

@@ -213,14 +213,41 @@ def backward_z(plan: FlowPlan, z_out: torch.Tensor, z_saved: Optional[torch.Tens
     return g_in
 
 
-def langevin_step(plan: FlowPlan, z: torch.Tensor, grad_g: Optional[torch.Tensor], noise: Optional[torch.Tensor],
+class PhiloxNoise:
+    """In-kernel N(0,1) noise for `langevin_step` (include/lsnf_flow.h `LsnfRng`): a pure function of
+    (seed, offset, row0 + row, column).  `offset` must differ from step to step (`.step()` returns the next one);
+    `row0` is the global index of the shard's first row, so that row-sharded chains draw what one GPU would;
+    `offset_dev` is an optional int64/uint64 device scalar added to `offset` (advance it inside a captured graph)."""
+    __slots__ = ("seed", "offset", "row0", "offset_dev")
+
+    def __init__(self, seed: int, offset: int = 0, row0: int = 0, offset_dev: Optional[torch.Tensor] = None):
+        self.seed, self.offset, self.row0, self.offset_dev = int(seed), int(offset), int(row0), offset_dev
+
+    def step(self, n: int = 1) -> "PhiloxNoise":
+        return PhiloxNoise(self.seed, self.offset + n, self.row0, self.offset_dev)
+
+    def _c(self):
+        mask = (1 << 64) - 1
+        dev = None if self.offset_dev is None else self.offset_dev.data_ptr()
+        return _lib.LsnfRng(self.seed & mask, self.offset & mask, dev, self.row0)
+
+
+def langevin_step(plan: FlowPlan, z: torch.Tensor, grad_g: Optional[torch.Tensor], noise,
                   step_size: float, *, inplace: bool = False, want_norms: bool = True):
     """One flow-prior Langevin update (train.py:316-329) in two launches: forward (keeps block outputs) and the
-    fused backward+update.  Returns (z_new, ll, gf_norm, gg_norm); ll is the log-prob of the INPUT z
+    fused backward+update.  `noise`: None, a (B, nz) tensor of N(0,1) draws, or a `PhiloxNoise` (drawn inside the
+    kernel).  Returns (z_new, ll, gf_norm, gg_norm); ll is the log-prob of the INPUT z
     (f_log_lkhd = -ll.sum(), train.py:320)."""
     lib = _lib.load()
     _need_cuda(z, "z")
     B = z.shape[0]
+    rng = None
+    if isinstance(noise, PhiloxNoise):
+        if noise.offset_dev is not None:
+            od = noise.offset_dev
+            if not od.is_cuda or od.dtype not in (torch.int64, torch.uint64) or od.numel() != 1:
+                raise LsnfError("offset_dev must be one 64-bit integer on the GPU")
+        rng, noise = ctypes.byref(noise._c()), None
     for name, t in (("grad_g", grad_g), ("noise", noise)):
         if t is not None:
             _need_cuda(t, name)
@@ -233,7 +260,8 @@ def langevin_step(plan: FlowPlan, z: torch.Tensor, grad_g: Optional[torch.Tensor
     gg = torch.empty(B, dtype=torch.float32, device=z.device) if (want_norms and grad_g is not None) else None
     with torch.cuda.device(z.device):
         rc = lib.lsnf_langevin_step(_ptr(plan.buf), plan.nz, plan.width, plan.depth, plan.coupling, B,
-                                    _ptr(z), _ptr(z1), _ptr(saved), _ptr(act), _ptr(grad_g), _ptr(noise), float(step_size),
+                                    _ptr(z), _ptr(z1), _ptr(saved), _ptr(act), _ptr(grad_g), _ptr(noise), rng,
+                                    float(step_size),
                                     _ptr(z_new), _ptr(gf), _ptr(gg), _stream_ptr(z.device))
     _lib.check(rc, "lsnf_langevin_step")
     return z_new, ll, gf, gg

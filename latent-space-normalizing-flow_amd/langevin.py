@@ -17,13 +17,16 @@ import torch.nn as nn
 
 def sample_langevin_post_z_with_flow(z, x, netG: nn.Module, netF, *, g_l_steps: int, g_l_step_size: float,
                                      g_llhd_sigma: float, g_l_with_noise: bool = True,
-                                     generator: Optional[torch.Generator] = None):
-    """Returns (z_k detached (B,nz,1,1), mean |z_grad_g|, mean |z_grad_f|, f_log_lkhd of the last step's input)."""
+                                     generator: Optional[torch.Generator] = None, philox=None):
+    """Returns (z_k detached (B,nz,1,1), mean |z_grad_g|, mean |z_grad_f|, f_log_lkhd of the last step's input).
+    Noise (train.py:325-326): `torch.randn` draws (optionally from `generator`), or, with `philox` =
+    `flow.PhiloxNoise(seed, offset, row0)`, drawn inside the update kernel (step k uses offset + k): no randn
+    launch, no (B, nz) noise tensor, and the same draws however the rows are sharded over GPUs."""
     z = z.clone().detach()
     B, nz = z.shape[0], z.shape[1]
     mse = nn.MSELoss(reduction="sum")
     gg_norm = gf_norm = f_log_lkhd = None
-    for _ in range(g_l_steps):
+    for k in range(g_l_steps):
         z.requires_grad_(True)
         x_hat = netG(z)                                                                      # train.py:312
         g_log_lkhd = 1.0 / (2.0 * g_llhd_sigma * g_llhd_sigma) * mse(x_hat, x)               # train.py:313
@@ -31,7 +34,8 @@ def sample_langevin_post_z_with_flow(z, x, netG: nn.Module, netF, *, g_l_steps: 
         z2d = z.detach().view(B, nz)
         noise = None
         if g_l_with_noise:                                                                   # train.py:325-326
-            noise = torch.randn(z2d.shape, device=z2d.device, dtype=z2d.dtype, generator=generator)
+            noise = philox.step(k) if philox is not None else \
+                torch.randn(z2d.shape, device=z2d.device, dtype=z2d.dtype, generator=generator)
         z_new, ll, gf, gg = netF.langevin_step(z2d, z_grad_g.reshape(B, nz), noise, g_l_step_size)   # :316-326
         f_log_lkhd = -ll.sum()                                                               # train.py:320
         gg_norm, gf_norm = gg.mean(), gf.mean()                                              # train.py:328-329

@@ -265,10 +265,13 @@ class _netF(nn.Module):
 
     def langevin_step(self, z, grad_g=None, noise=None, step_size=0.1, inplace=False):
         """z <- z - 0.5 s^2 (grad_g + d(-sum ll)/dz) + s*noise (train.py:316-326), flow part fused into two launches.
+        noise: None, a tensor of N(0,1) draws, or a `flow.PhiloxNoise` (drawn inside the kernel).
         Returns (z_new, ll_of_input_z, |grad_f| per row, |grad_g| per row or None)."""
+        if isinstance(noise, torch.Tensor):
+            noise = noise.detach().contiguous()
         return flow.langevin_step(self._plan(), z.detach().contiguous(),
-                                  None if grad_g is None else grad_g.detach().contiguous(),
-                                  None if noise is None else noise.detach().contiguous(), step_size, inplace=inplace)
+                                  None if grad_g is None else grad_g.detach().contiguous(), noise, step_size,
+                                  inplace=inplace)
 
     def mle_grads(self, z, accumulate: bool = False):
         """Fused flow-MLE gradients (train.py:404-411): loss_f = -mean_b ll(z_b) and d loss_f / d theta written to

@@ -137,3 +137,53 @@ def test_sampler_and_mle_step_harness_vs_oracle(lsnf, gpu_device):
     l2 = lsnf.langevin.flow_mle_step(net, opt, zk, f_max_norm=100.0, fused=True)
     l3 = lsnf.langevin.flow_mle_step(net, opt, zk, f_max_norm=100.0, fused=True)
     assert l3.item() < l2.item() <= l1.item()
+
+
+@pytest.mark.parametrize("nz,width,B", [(100, 64, 77), (128, 64, 130), (20, 12, 33), (100, 128, 40)])
+def test_in_kernel_philox_noise_matches_oracle(lsnf, kernels, gpu_device, nz, width, B):
+    """lsnf_langevin_step with the in-kernel generator == the same step fed the oracle's noise tensor."""
+    from oracle.philox_oracle import langevin_noise
+    depth = 5
+    p = O.init_params(nz, width, depth, seed=nz + width)
+    plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
+    gen = torch.Generator().manual_seed(B)
+    z = torch.randn(B, nz, generator=gen).to(gpu_device)
+    gg = torch.randn(B, nz, generator=gen).to(gpu_device)
+    s, seed, off = 0.1, 0x1234_5678_9ABC_DEF1, (7 << 32) + 5
+    rng = lsnf.flow.PhiloxNoise(seed, off)
+    z_rng, ll_a, gf_a, gg_a = lsnf.langevin_step(plan, z, gg, rng, s)
+    noise = torch.from_numpy(langevin_noise(B, nz, seed, off)).float().to(gpu_device)
+    z_ten, ll_b, gf_b, gg_b = lsnf.langevin_step(plan, z, gg, noise, s)
+    assert torch.equal(ll_a, ll_b) and torch.equal(gf_a, gf_b) and torch.equal(gg_a, gg_b)
+    # v_log_f32 / v_sin_f32 / v_cos_f32 vs float64 libm: a few 1e-6 on a normal, times the step size
+    assert (z_rng - z_ten).abs().max().item() <= 5e-6
+    got = (z_rng - lsnf.langevin_step(plan, z, gg, None, s)[0]) / s          # the draws themselves
+    assert (got - noise).abs().max().item() <= 1e-4
+    # sharded rows with row0 draw what the full batch draws, bit for bit; other offsets / seeds do not
+    cut = B // 3
+    lo = lsnf.langevin_step(plan, z[:cut].contiguous(), gg[:cut].contiguous(), rng, s)[0]
+    hi = lsnf.langevin_step(plan, z[cut:].contiguous(), gg[cut:].contiguous(),
+                            lsnf.flow.PhiloxNoise(seed, off, row0=cut), s)[0]
+    assert torch.equal(torch.cat([lo, hi]), z_rng)
+    assert not torch.equal(lsnf.langevin_step(plan, z, gg, rng.step(), s)[0], z_rng)
+    # device-side counter (for captured graphs): offset = host offset + *offset_dev
+    ctr = torch.tensor([3], dtype=torch.int64, device=gpu_device)
+    z_ctr = lsnf.langevin_step(plan, z, gg, lsnf.flow.PhiloxNoise(seed, off - 3, offset_dev=ctr), s)[0]
+    assert torch.equal(z_ctr, z_rng)
+    with pytest.raises(lsnf.LsnfError):
+        lsnf.flow.langevin_step(plan, z, gg, lsnf.flow.PhiloxNoise(seed, off, row0=-1), s)
+
+
+def test_in_kernel_philox_noise_full_size_moments(lsnf, gpu_device):
+    """B = 65536 x nz = 128 draws (throughput kernel): moments, and no correlation between neighbours."""
+    nz, width, depth, B = 128, 64, 5, 65536
+    p = O.init_params(nz, width, depth, seed=1)
+    plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
+    z = torch.randn(B, nz, generator=torch.Generator().manual_seed(3)).to(gpu_device)
+    base = lsnf.langevin_step(plan, z, None, None, 0.25)[0]
+    n = ((lsnf.langevin_step(plan, z, None, lsnf.flow.PhiloxNoise(99, 1), 0.25)[0] - base) / 0.25).double()
+    assert abs(n.mean().item()) < 2e-3 and abs(n.var().item() - 1.0) < 3e-3
+    assert abs((n ** 4).mean().item() - 3.0) < 0.03
+    assert abs((n[:, 1:] * n[:, :-1]).mean().item()) < 2e-3 and abs((n[1:] * n[:-1]).mean().item()) < 2e-3
+    n2 = ((lsnf.langevin_step(plan, z, None, lsnf.flow.PhiloxNoise(99, 2), 0.25)[0] - base) / 0.25).double()
+    assert abs((n * n2).mean().item()) < 2e-3

@@ -110,3 +110,23 @@ def test_init_params_shapes_and_roundtrip():
     J = J.reshape(10, 10)
     _, ld64 = O.flow_forward(p64, z0, torch.zeros(1, dtype=torch.float64))
     assert abs(torch.log(torch.abs(torch.det(J))).item() - ld64.item()) < 1e-10
+
+
+def test_philox_oracle_known_answers_and_moments():
+    """The noise oracle (oracle/philox_oracle.py) against the Random123 known-answer vectors of Philox4x32-10
+    (kat_vectors of the Random123 distribution: counter, key -> output), plus the moments of the normals."""
+    from oracle.philox_oracle import philox4x32_10, langevin_noise
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        assert tuple(int(x) for x in philox4x32_10(*ctr, *key)) == want
+    n = langevin_noise(2048, 100, seed=11, offset=5)
+    assert n.shape == (2048, 100) and np.isfinite(n).all()
+    assert abs(n.mean()) < 0.01 and abs(n.var() - 1.0) < 0.02
+    assert abs(np.mean(n ** 3)) < 0.05 and abs(np.mean(n ** 4) - 3.0) < 0.15
+    # a pure function of (seed, offset, global row, column): row windows and offsets compose
+    assert np.array_equal(langevin_noise(48, 100, 11, 5, row0=2000), n[2000:])
+    assert not np.array_equal(langevin_noise(8, 100, 11, 6), n[:8])
+    assert not np.array_equal(langevin_noise(8, 100, 12, 5), n[:8])
