@@ -64,6 +64,18 @@ const char* lsnf_last_error(void);
  * rows < 0 only queries.  Returns the previous value (default 16384, or the LSNF_SMALL_MAX environment variable). */
 int lsnf_set_small_batch_max(int rows);
 
+/* Arithmetic of the GEMMs in the throughput forward kernel (batches above the small-batch threshold):
+ *   LSNF_MATH_FP32   : fp32 MFMA (v_mfma_f32_32x32x2_f32)
+ *   LSNF_MATH_BF16X3 : both operands split error-free into three bf16 terms, six bf16 MFMAs per product with fp32
+ *                      accumulation (csrc/lsnf_fwd3.hip).  Same accuracy class as fp32 MFMA (dropped terms are
+ *                      <= 2^-26 |w||x|); results agree with LSNF_MATH_FP32 to fp32 rounding, not bit for bit.
+ * mode < 0 only queries.  Returns the previous mode (default LSNF_MATH_DEFAULT, or the LSNF_MATH environment
+ * variable "fp32" / "bf16x3"). */
+#define LSNF_MATH_FP32 0
+#define LSNF_MATH_BF16X3 1
+#define LSNF_MATH_DEFAULT LSNF_MATH_FP32
+int lsnf_set_math_mode(int mode);
+
 /* Device query: writes the gfx arch name (e.g. "gfx950") of device `device`; LSNF_E_NODEVICE
  * if there is none.  Only call that touches the device without doing work. */
 int lsnf_device_arch(int device, char* buf, size_t buflen);

@@ -25,6 +25,7 @@ _SIGNATURES = {
     "lsnf_abi_version": (c_int, []),
     "lsnf_last_error": (c_char_p, []),
     "lsnf_set_small_batch_max": (c_int, [c_int]),
+    "lsnf_set_math_mode": (c_int, [c_int]),
     "lsnf_device_arch": (c_int, [c_int, c_char_p, c_size_t]),
     "lsnf_plan_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "lsnf_prepare_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),

@@ -21,6 +21,10 @@ hipError_t lsnf_launch_forward(const LsnfGeo& g, const float* plan, int first_bl
                                const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
                                hipStream_t stream);
+hipError_t lsnf_launch_forward3(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
+                                const float* z_in, const float* objective, float* z_out, float* logdet_out,
+                                float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
+                                hipStream_t stream);
 hipError_t lsnf_launch_small_forward(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                      const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                      float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
@@ -75,6 +79,16 @@ int small_batch_max() {
     return g_small_max;
 }
 
+// arithmetic of the throughput forward's GEMMs (LSNF_MATH=fp32|bf16x3 overrides the default)
+int g_math = -1;
+int math_mode() {
+    if (g_math < 0) {
+        const char* e = getenv("LSNF_MATH");
+        g_math = (e && !strcmp(e, "bf16x3")) ? LSNF_MATH_BF16X3 : (e && !strcmp(e, "fp32")) ? LSNF_MATH_FP32 : LSNF_MATH_DEFAULT;
+    }
+    return g_math;
+}
+
 int geo_or_fail(LsnfGeo* g, int nz, int width, int depth, int coupling) {
     if (lsnf_geo_init(g, nz, width, depth, coupling))
         return fail(LSNF_E_GEOMETRY, "unsupported geometry nz=%d width=%d depth=%d coupling=%d "
@@ -91,6 +105,11 @@ int lsnf_abi_version(void) { return LSNF_ABI_VERSION; }
 int lsnf_set_small_batch_max(int rows) {
     const int prev = small_batch_max();
     if (rows >= 0) g_small_max = rows;
+    return prev;
+}
+int lsnf_set_math_mode(int mode) {
+    const int prev = math_mode();
+    if (mode == LSNF_MATH_FP32 || mode == LSNF_MATH_BF16X3) g_math = mode;
     return prev;
 }
 const char* lsnf_last_error(void) { return g_err; }
@@ -156,11 +175,19 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
     if (stats && (reinterpret_cast<uintptr_t>(stats) & 7u)) return fail(LSNF_E_ARG, "lsnf_forward: stats must be 8-byte aligned");
     // batch-size dispatch: latency kernel (32 rows per workgroup, stages split over the 4 waves) below the
     // crossover, throughput kernel (128 rows per workgroup, weights shared through LDS) above it
-    hipError_t e = (B <= small_batch_max())
-        ? lsnf_launch_small_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
-                                    z_saved, act_saved, stats, vec4, (hipStream_t)stream)
-        : lsnf_launch_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
-                              z_saved, act_saved, stats, vec4, (hipStream_t)stream);
+    hipError_t e;
+    if (B <= small_batch_max()) {
+        e = lsnf_launch_small_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
+                                      z_saved, act_saved, stats, vec4, (hipStream_t)stream);
+    } else {
+        e = hipErrorInvalidValue;
+        if (math_mode() == LSNF_MATH_BF16X3)      // error-free split on the bf16 matrix pipe (lsnf_fwd3.hip)
+            e = lsnf_launch_forward3(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
+                                     z_saved, act_saved, stats, vec4, (hipStream_t)stream);
+        if (e == hipErrorInvalidValue)            // fp32 MFMA kernel (also: stacks too deep for fwd3's LDS budget)
+            e = lsnf_launch_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
+                                    z_saved, act_saved, stats, vec4, (hipStream_t)stream);
+    }
     if (e != hipSuccess) return hip_fail(e, "lsnf_forward launch");
     return LSNF_OK;
 }

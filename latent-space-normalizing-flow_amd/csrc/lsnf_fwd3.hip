@@ -1,0 +1,339 @@
+// lsnf_fwd3.hip -- the fused forward of lsnf_fwd.hip with its GEMMs on the bf16 matrix pipe at fp32 accuracy.
+//
+// Same math, same interface and same register layout as lsnf_fwd.hip (replaces reference model.py:473-483 +
+// train.py:317-319); what changes is how a product  acc += W^T x  is evaluated.  fp32 MFMA
+// (v_mfma_f32_32x32x2_f32) peaks at 157 TFLOP/s on MI355X, the bf16 MFMA (v_mfma_f32_32x32x16_bf16) at 2.5 PFLOP/s,
+// 16x.  Both operands are split error-free into three bf16 terms,
+//       w = w1 + w2 + w3,   x = x1 + x2 + x3      (each term the round-to-nearest bf16 of what is left),
+// and the product keeps the six terms of weight >= 2^-18:
+//       w x ~= w1 x1 + w1 x2 + w2 x1 + w2 x2 + w1 x3 + w3 x1,
+// every bf16 x bf16 product being exact in the MFMA's fp32 accumulator.  The dropped terms are <= 2^-26 |w||x|,
+// below the 2^-24 rounding of an fp32 product: the log-prob error against float64 is the same 2-3e-7 as the fp32
+// MFMA path's (tools/study/split_bf16_accuracy.py, tests/test_gpu_forward.py) -- this is NOT a reduced-precision
+// mode.  Six MFMAs of K = 16 replace eight of K = 2 x 8: 2.6x the fp32 MFMA rate (tools/micro/mfma_bf16.hip);
+// the weights are split once in lsnf_prepare (plan region off_f3_panels, 6 KiB per 32x32 block instead of 4),
+// the activations on the fly (4.5 VALU per element: v_cvt_pk_bf16_f32, shift/and, v_pk_add_f32).
+//
+// Work decomposition: one workgroup of 8 waves per CU (the two 48 KiB weight buffers do not fit twice), wave = 32
+// samples; weights stream L2 -> LDS by LDS-DMA in panel pairs exactly as in lsnf_fwd.hip.  Because the k-slot j of
+// lane-half h in k-step s is accumulator register 8*s + j (lsnf_layout.h), an output tile converted to bf16 pairs in
+// register order is directly the next GEMM's B operand.
+#include "lsnf_device.h"
+
+namespace {
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int F3_WAVES = 8;
+
+template <int HT_, int WT_>
+struct Fwd3Cfg : LsnfStackCfg<HT_, WT_> {
+    using S = LsnfStackCfg<HT_, WT_>;
+    static constexpr int F = LSNF_FRAG3_FLOATS;
+    static constexpr int OFF3_S2 = F * S::P1 * S::KT1;
+    static constexpr int OFF3_S3 = OFF3_S2 + F * S::P2 * S::KT2;
+    static constexpr int OFF3_S4 = OFF3_S3 + F * S::P3 * S::KT3;
+    static constexpr int BLOCK3 = OFF3_S4 + F * S::P4 * S::KT4;
+    static constexpr int SLOT3 = 2 * S::MAXKT * F;            // LDS floats of one panel pair
+    static constexpr int CONST_FLOATS = S::FWD_CONST;
+};
+
+struct Fwd3Args {
+    const float* consts; const float* panels3;
+    const float* z_in; const float* objective;
+    float* z_out; float* logdet_out; float* ll_out; float* z_saved; float* act_saved;
+    int B, nz, half, n_blocks, vec4;
+    double* stats;
+};
+
+// the three bf16 terms of one k-step (16 features of one 32-sample tile), B-operand order
+struct Split3 { bf16x8 p[3]; };
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    const f32x2v v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));      // v_cvt_pk_bf16_f32 (RNE)
+}
+// registers 8*s .. 8*s+7 of an activation tile -> x1, x2, x3 of k-step s
+__device__ __forceinline__ void split_kstep(const f32x16& x, int s, Split3& out) {
+    u32x4 w[3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float a = x[8 * s + 2 * q], b = x[8 * s + 2 * q + 1];
+        const unsigned p1 = pk_bf16(a, b);
+        a -= __builtin_bit_cast(float, p1 << 16); b -= __builtin_bit_cast(float, p1 & 0xffff0000u);
+        const unsigned p2 = pk_bf16(a, b);
+        a -= __builtin_bit_cast(float, p2 << 16); b -= __builtin_bit_cast(float, p2 & 0xffff0000u);
+        w[0][q] = p1; w[1][q] = p2; w[2][q] = pk_bf16(a, b);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out.p[i] = __builtin_bit_cast(bf16x8, w[i]);
+}
+template <int KT>
+__device__ __forceinline__ void split_tiles(const f32x16* x, Split3* out) {   // out[2*KT]
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) { split_kstep(x[kt], 0, out[2 * kt]); split_kstep(x[kt], 1, out[2 * kt + 1]); }
+}
+
+// LDS-DMA of KB KiB (1 KiB per wave-instruction), as lsnf_issue_panel
+template <int KB>
+__device__ __forceinline__ void issue_kib(const float* __restrict__ gsrc, float* lbuf, int wave, int lane) {
+    constexpr int PER_WAVE = (KB + F3_WAVES - 1) / F3_WAVES;
+#pragma unroll
+    for (int s = 0; s < PER_WAVE; ++s) {
+        const int seg = s * F3_WAVES + wave;
+        if (KB % F3_WAVES == 0 || seg < KB) {      // wave-uniform
+            __builtin_amdgcn_global_load_lds((const LSNF_AS1 void*)(gsrc + seg * 256 + lane * 4),
+                                             (LSNF_AS3 void*)(lbuf + seg * 256), 16, 0, 0);
+        }
+    }
+}
+struct Pipe3 {
+    float* buf0; int slot, cur, wave, lane;
+    template <int KB> __device__ __forceinline__ void prime(const float* src) { issue_kib<KB>(src, buf0, wave, lane); cur = 0; }
+    template <int KB_NEXT> __device__ __forceinline__ const float* acquire(const float* next) {
+        lsnf_panel_barrier();
+        if (next != nullptr) issue_kib<KB_NEXT>(next, buf0 + (cur ^ 1) * slot, wave, lane);
+        const float* ready = buf0 + cur * slot;
+        cur ^= 1;
+        return ready;
+    }
+};
+__device__ __forceinline__ constexpr int first_kib(int NT, int KT) { return 6 * KT * (NT >= 2 ? 2 : 1); }
+
+// the six kept terms (weight part, activation part), smallest first
+#define LSNF_F3_TERMS(M) M(2, 0) M(0, 2) M(1, 1) M(1, 0) M(0, 1) M(0, 0)
+
+// two n-tiles x KT k-tiles: acc0/acc1 += W^T in.  Per k-step 6 fragment reads (3 parts x 2 tiles) feed 12 MFMAs;
+// the next k-step's reads are issued before the current MFMAs (second register set).
+template <int KT, bool PAIR>
+__device__ __forceinline__ void panel_mma3(f32x16& acc0, f32x16& acc1, const Split3* in, const float* lbuf, int lane) {
+    const bf16x8* wp = reinterpret_cast<const bf16x8*>(lbuf) + lane;
+    constexpr int T1 = KT * 6 * 64;                           // 16-byte offset of tile 1's panel
+    constexpr int NR = PAIR ? 6 : 3;
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 a[3], b[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) { a[p] = wp[p * 64]; b[p] = PAIR ? wp[T1 + p * 64] : a[p]; }
+    __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+#pragma unroll
+    for (int ks = 0; ks < 2 * KT; ++ks) {
+        bf16x8 na[3], nb[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { na[p] = a[p]; nb[p] = b[p]; }
+        if (ks + 1 < 2 * KT) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) { na[p] = wp[((ks + 1) * 3 + p) * 64]; if (PAIR) nb[p] = wp[T1 + ((ks + 1) * 3 + p) * 64]; }
+        }
+#define LSNF_F3_MMA(WI, XI)                                                                              \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[WI], in[ks].p[XI], acc0, 0, 0, 0);             \
+        if (PAIR) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[WI], in[ks].p[XI], acc1, 0, 0, 0);
+        LSNF_F3_TERMS(LSNF_F3_MMA)
+#undef LSNF_F3_MMA
+        if (ks + 1 < 2 * KT) __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, PAIR ? 12 : 6, 0);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { a[p] = na[p]; b[p] = nb[p]; }
+    }
+}
+
+// one GEMM stage out[t] = post(init(t) + W_t^T in), streamed as panel pairs (cf. lsnf_gemm_stage)
+template <int NT, int KT, int NEXT_KIB, class Init, class Post>
+__device__ __forceinline__ void gemm_stage3(Pipe3& pipe, const float* gsrc, const float* gnext, f32x16* out, const Split3* in,
+                                            Init&& init, Post&& post) {
+    constexpr int NSP = (NT + 1) / 2;
+    lsnf_static_for<NSP>([&](auto qc) {
+        constexpr int q = decltype(qc)::value, t0 = 2 * q, cnt = (NT - t0 >= 2) ? 2 : 1;
+        const float* lb;
+        if constexpr (q + 1 < NSP) {
+            constexpr int cn = (NT - (t0 + 2) >= 2) ? 2 : 1;
+            lb = pipe.template acquire<6 * KT * cn>(gsrc + (t0 + 2) * KT * LSNF_FRAG3_FLOATS);
+        } else {
+            lb = pipe.template acquire<NEXT_KIB>(gnext);
+        }
+        out[t0] = init(t0);
+        if constexpr (cnt == 2) {
+            out[t0 + 1] = init(t0 + 1);
+            panel_mma3<KT, true>(out[t0], out[t0 + 1], in, lb, pipe.lane);
+            out[t0 + 1] = post(out[t0 + 1], t0 + 1);
+        } else {
+            panel_mma3<KT, false>(out[t0], out[t0], in, lb, pipe.lane);
+        }
+        out[t0] = post(out[t0], t0);
+    });
+}
+
+template <class C>
+__global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3_kernel(const Fwd3Args a) {
+    constexpr int THREADS = 64 * F3_WAVES;
+    constexpr int HT = C::HT, WT = C::WT, NZT = C::NZT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* cst = smem;                                         // n_blocks * CONST_FLOATS
+    float* buf0 = smem + a.n_blocks * C::CONST_FLOATS;         // 2 x SLOT3
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int m = lane & 31, h = lane >> 5;
+
+    Pipe3 pipe;
+    pipe.buf0 = buf0; pipe.slot = C::SLOT3; pipe.wave = wave; pipe.lane = lane;
+    pipe.template prime<first_kib(C::P1, C::KT1)>(a.panels3);
+    for (int i = tid; i < a.n_blocks * C::CONST_FLOATS; i += THREADS) cst[i] = a.consts[i];
+
+    const long sample = ((long)blockIdx.x * F3_WAVES + wave) * 32 + m;
+    const bool live = sample < a.B;
+    const long row = live ? sample : (long)a.B - 1;
+
+    f32x16 x[NZT];
+    lsnf_load_rows<HT>(x, a.z_in, row, a.nz, a.half, h, a.vec4);
+    float ell = a.objective ? a.objective[row] : 0.0f;
+
+    const LsnfActLayout al = lsnf_act_layout(a.B, HT, WT);
+    const size_t wtile = (size_t)blockIdx.x * F3_WAVES + wave;
+    for (int blk = 0; blk < a.n_blocks; ++blk) {
+        float* act = (a.act_saved && wtile * 32 < (size_t)a.B)
+                         ? a.act_saved + (size_t)blk * al.per_block + wtile * al.per_tile : nullptr;
+        const float* cb = cst + blk * C::CONST_FLOATS;
+        const float* gblk = a.panels3 + (size_t)blk * C::BLOCK3;
+        const bool more = blk + 1 < a.n_blocks;
+        const float* gnext = more ? gblk + C::BLOCK3 : nullptr;
+        auto keep = [](f32x16 acc, int) { return acc; };
+        auto relu = [](f32x16 acc, int) { return lsnf_relu16(acc); };
+
+        // ---- S1: v = Wa^T x + ca  (actnorm model.py:244,268 folded into the 1x1 conv :187) ----
+        f32x16 v[NZT];
+        {
+            Split3 xs[2 * NZT];
+            split_tiles<NZT>(x, xs);
+            gemm_stage3<C::P1, C::KT1, first_kib(C::P2, C::KT2)>(
+                pipe, gblk, gblk + C::OFF3_S2, v, xs, [&](int t) { return lsnf_bias_init(cb + 32 * t, h); }, keep);
+        }
+        if (!more && live) {     // last block: the v1 half is final (model.py:422) -- store it under the MFMAs of S2..S4
+            float* zo = a.z_out + sample * (long)a.nz;
+#pragma unroll
+            for (int t = 0; t < HT; ++t) lsnf_store_tile<HT>(t, v[t], zo, a.half, h, a.vec4);
+        }
+        ell = ell + cb[32 * C::NP + 0];          // sum(3*logs)  (model.py:273-276)
+        ell = ell + cb[32 * C::NP + 1];          // log|det W|   (model.py:182,189)
+        // ---- S2: h1 = relu(actnorm(v1 @ W1))  (model.py:326-328,307) ----
+        f32x16 h1[WT];
+        {
+            Split3 vs[2 * HT];
+            split_tiles<HT>(v, vs);
+            gemm_stage3<C::P2, C::KT2, first_kib(C::P3, C::KT3)>(
+                pipe, gblk + C::OFF3_S2, gblk + C::OFF3_S3, h1, vs,
+                [&](int t) { return lsnf_bias_init(cb + 32 * (C::P1 + t), h); }, relu);
+        }
+        if (act) {
+#pragma unroll
+            for (int t = 0; t < WT; ++t) *lsnf_act_mask_ptr(act, al.mask_off, t, lane) = lsnf_posmask16(h1[t]);
+        }
+        // ---- S3: h2 = relu(actnorm(h1 @ W2))  (model.py:326-328,308) ----
+        f32x16 h2[WT];
+        {
+            Split3 hs[2 * WT];
+            split_tiles<WT>(h1, hs);
+            gemm_stage3<C::P3, C::KT3, first_kib(C::P4, C::KT4)>(
+                pipe, gblk + C::OFF3_S3, gblk + C::OFF3_S4, h2, hs,
+                [&](int t) { return lsnf_bias_init(cb + 32 * (C::P1 + C::P2 + t), h); }, relu);
+        }
+        if (act) {
+#pragma unroll
+            for (int t = 0; t < WT; ++t) *lsnf_act_mask_ptr(act, al.mask_off, WT + t, lane) = lsnf_posmask16(h2[t]);
+        }
+        // ---- S4: shift t / pre-sigmoid p = fc_zeros(h2), de-interleaved (model.py:347-349,411-413) ----
+        f32x16 tp[2 * HT];
+        {
+            Split3 hs[2 * WT];
+            split_tiles<WT>(h2, hs);
+            gemm_stage3<C::P4, C::KT4, first_kib(C::P1, C::KT1)>(
+                pipe, gblk + C::OFF3_S4, gnext, tp, hs,
+                [&](int t) { return lsnf_bias_init(cb + 32 * (C::P1 + C::P2 + C::P3 + t), h); }, keep);
+        }
+        // ---- coupling + per-sample log-scale reduction (model.py:414-418), concat (:422) ----
+        float lsum = 0.0f;
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+            x[t] = v[t];
+            f32x16 sg;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sig, l2;
+                lsnf_sigmoid_log2(tp[HT + t][r], sig, l2);
+                x[HT + t][r] = (v[HT + t][r] + tp[t][r]) * sig;
+                sg[r] = sig;
+                lsum += l2;
+            }
+            if (act) lsnf_act_store_sigma(act, t, sg, lane);
+        }
+        ell = ell + -0.6931471805599453f * lsnf_pair_sum(lsum);
+        if (a.z_saved != nullptr && more && live)
+            lsnf_store_rows<HT>(x, a.z_saved + (size_t)blk * a.B * a.nz, sample, a.nz, a.half, h, a.vec4);
+    }
+
+    // ---- epilogue: z_out, logdet, ll = -0.5*sum z^2 + log(2pi) + logdet (train.py:317-319) ----
+    float ss = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NZT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ss += x[t][r] * x[t][r];
+    ss = lsnf_pair_sum(ss);
+    if (live) {
+        float* zo = a.z_out + sample * (long)a.nz;
+#pragma unroll
+        for (int t = HT; t < NZT; ++t) lsnf_store_tile<HT>(t, x[t], zo, a.half, h, a.vec4);
+        if (h == 0) {
+            a.logdet_out[sample] = ell;
+            if (a.ll_out) a.ll_out[sample] = (-0.5f * ss + 1.8378770664093453f) + ell;
+        }
+    }
+    if (a.stats) {   // kernel-uniform: batch sums of ll and logdet, one pair of fp64 atomics per workgroup
+        float sl = (live && h == 0) ? ((-0.5f * ss + 1.8378770664093453f) + ell) : 0.0f;
+        float sd = (live && h == 0) ? ell : 0.0f;
+        double dl = (double)sl, dd = (double)sd;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { dl += __shfl_xor(dl, o, 64); dd += __shfl_xor(dd, o, 64); }
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(buf0);
+        if (lane == 0) { red[2 * wave] = dl; red[2 * wave + 1] = dd; }
+        __syncthreads();
+        if (tid == 0) {
+            double tl = 0.0, td = 0.0;
+            for (int w = 0; w < F3_WAVES; ++w) { tl += red[2 * w]; td += red[2 * w + 1]; }
+            lsnf_publish_stats(a.stats, tl, td, a.B);
+        }
+    }
+}
+
+template <class C>
+hipError_t launch_fwd3(const Fwd3Args& a, hipStream_t stream) {
+    const size_t lds = ((size_t)a.n_blocks * C::CONST_FLOATS + 2 * (size_t)C::SLOT3) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto kern = lsnf_fwd3_kernel<C>;
+    static unsigned long long lds_ok = 0;
+    if (hipError_t e = lsnf_allow_big_lds((const void*)kern, &lds_ok); e != hipSuccess) return e;
+    const unsigned grid = (unsigned)((a.B + 32 * F3_WAVES - 1) / (32 * F3_WAVES));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * F3_WAVES), lds, stream, a);
+    return hipGetLastError();
+}
+}  // namespace
+
+// host-side dispatcher (called from lsnf_api.hip); hipErrorInvalidValue = this geometry is not covered
+hipError_t lsnf_launch_forward3(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
+                                const float* z_in, const float* objective, float* z_out, float* logdet_out,
+                                float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
+                                hipStream_t stream) {
+    Fwd3Args a;
+    a.stats = stats;
+    a.act_saved = act_saved ? act_saved + (size_t)first_block * lsnf_act_layout(B, g.HT, g.WT).per_block : nullptr;
+    a.consts = plan + g.off_fwd_const + (size_t)first_block * g.fwd_const_floats;
+    a.panels3 = plan + g.off_f3_panels + (size_t)first_block * g.f3_block_floats;
+    a.z_in = z_in; a.objective = objective; a.z_out = z_out; a.logdet_out = logdet_out; a.ll_out = ll_out;
+    a.z_saved = z_saved; a.B = B; a.nz = g.nz; a.half = g.half; a.n_blocks = n_blocks; a.vec4 = vec4;
+    if (g.HT == 1 && g.WT == 1) return launch_fwd3<Fwd3Cfg<1, 1>>(a, stream);
+    if (g.HT == 2 && g.WT == 2) return launch_fwd3<Fwd3Cfg<2, 2>>(a, stream);
+    if (g.HT == 2 && g.WT == 4) return launch_fwd3<Fwd3Cfg<2, 4>>(a, stream);
+    return hipErrorInvalidValue;
+}

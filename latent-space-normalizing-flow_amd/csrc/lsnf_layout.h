@@ -21,6 +21,13 @@
 #define LSNF_MAX_DEPTH 16
 #define LSNF_TILE 32
 #define LSNF_FRAG_FLOATS 1024 /* one (nt,kt) 32x32 fragment block */
+// Split-bf16 forward stream (lsnf_fwd3.hip): the same (nt,kt) block as THREE bf16 matrices w = w1 + w2 + w3 (each the
+// round-to-nearest bf16 of what the previous ones left), in the A-operand order of v_mfma_f32_32x32x16_bf16:
+//   dword[((s*3 + part)*64 + lane)*4 + jw] = pack(bf16 part of M[k(2jw)][n], M[k(2jw+1)][n]),  n = 32*nt + (lane&31),
+//   k(j) = 32*kt + 16*s + (j&3) + 8*(j>>2) + 4*(lane>>5)      (s = k-step 0/1, j = 0..7)
+// i.e. k-slot j of lane-half h in k-step s is accumulator register 8*s + j of that lane-half -- an output tile
+// converted to bf16 pairs in register order is directly the next GEMM's B operand.
+#define LSNF_FRAG3_FLOATS 1536 /* 2 k-steps x 3 parts x 1 KiB, in 4-byte units */
 
 struct LsnfGeo {
     int nz, half, width, depth, coupling;
@@ -38,6 +45,8 @@ struct LsnfGeo {
     size_t off_inv_const, off_inv_panels;
     size_t off_bwd_const, off_bwd_panels;
     size_t off_winv;            // depth * nz*nz fp32 W^-1 (natural layout; used by d log|det W|/dW)
+    int f3_block_floats;        // split-bf16 forward panels per block (same tile order as the forward stream)
+    size_t off_f3_panels;
     size_t total_floats;
 };
 
@@ -108,6 +117,9 @@ static inline int lsnf_geo_init(LsnfGeo* g, int nz, int width, int depth, int co
     g->off_bwd_const = o;
     g->off_bwd_panels = o; o += (size_t)depth * g->bwd_block_floats;
     g->off_winv = o;       o += (size_t)depth * nz * nz;
+    o = (o + 255) & ~(size_t)255;
+    g->f3_block_floats = LSNF_FRAG3_FLOATS * (NZT * NZT + WT * HT + WT * WT + 2 * HT * WT);
+    g->off_f3_panels = o;  o += (size_t)depth * g->f3_block_floats;
     o = (o + 255) & ~(size_t)255;
     g->total_floats = o;
     return 0;

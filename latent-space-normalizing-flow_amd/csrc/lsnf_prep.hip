@@ -236,6 +236,32 @@ __device__ static inline void frag_decode(int q, int KT, int* k, int* n) {
     *n = 32 * nt + (lane & 31);
 }
 
+// split-bf16 stream: dword index inside a stage's panels -> the two (k, n) it packs and which part (0..2)
+__device__ static inline void frag3_decode(int q, int KT, int* k0, int* k1, int* n, int* part) {
+    const int per_panel = KT * LSNF_FRAG3_FLOATS;
+    const int nt = q / per_panel; int r = q % per_panel;
+    const int kt = r / LSNF_FRAG3_FLOATS; r %= LSNF_FRAG3_FLOATS;
+    const int sp = r / 256; r %= 256;                 // s*3 + part
+    const int s = sp / 3, lane = r / 4, jw = r % 4;
+    *part = sp % 3;
+    const int j0 = 2 * jw, j1 = 2 * jw + 1, h = lane >> 5;
+    *k0 = 32 * kt + 16 * s + (j0 & 3) + 8 * (j0 >> 2) + 4 * h;
+    *k1 = 32 * kt + 16 * s + (j1 & 3) + 8 * (j1 >> 2) + 4 * h;
+    *n = 32 * nt + (lane & 31);
+}
+// round-to-nearest-even bf16 of a float, as its 16-bit pattern (finite inputs)
+__device__ static inline unsigned bf16_rne_bits(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+// part p (0..2) of the error-free split w = w1 + w2 + w3 of the fp32 value the fp32 stream holds
+__device__ static inline unsigned bf16_part_bits(double v, int part) {
+    float r = (float)v;
+    unsigned b = bf16_rne_bits(r);
+    for (int i = 0; i < part; ++i) { r = r - __uint_as_float(b << 16); b = bf16_rne_bits(r); }
+    return b & 0xFFFFu;
+}
+
 // bias block order inside a stage: index = nt*32 + h*16 + r  <->  feature 32*nt + o(r,h)
 __device__ static inline int bias_feature(int i) {
     const int nt = i / 32, h = (i % 32) / 16, r = i % 16;
@@ -251,8 +277,8 @@ __global__ __launch_bounds__(256) void lsnf_pack_kernel(LsnfParamPtrs pp, LsnfGe
     // region sizes for this block
     const int n_fc = g.fwd_const_floats, n_fp = g.fwd_block_floats;
     const int n_ic = g.inv_const_floats, n_ip = g.inv_block_floats;
-    const int n_bp = g.bwd_block_floats, n_wi = nz * nz;
-    const int total = n_fc + n_fp + n_ic + n_ip + n_bp + n_wi;
+    const int n_bp = g.bwd_block_floats, n_wi = nz * nz, n_f3 = g.f3_block_floats;
+    const int total = n_fc + n_fp + n_ic + n_ip + n_bp + n_wi + n_f3;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
         int q = idx;
         if (q < n_fc) {                     // ---- forward constants
@@ -316,7 +342,19 @@ __global__ __launch_bounds__(256) void lsnf_pack_kernel(LsnfParamPtrs pp, LsnfGe
             continue;
         }
         q -= n_bp;
-        plan[g.off_winv + (size_t)blk * n_wi + q] = (float)sb[q];   // W^-1, natural layout
+        if (q < n_wi) { plan[g.off_winv + (size_t)blk * n_wi + q] = (float)sb[q]; continue; }   // W^-1, natural layout
+        q -= n_wi;
+        {                                   // ---- split-bf16 forward panels (same matrices as the forward stream)
+            unsigned* dst = reinterpret_cast<unsigned*>(plan + g.off_f3_panels + (size_t)blk * n_f3);
+            int r = q, k0, k1, n, part, stage, KT;
+            const int s1 = LSNF_FRAG3_FLOATS * NZT * NZT, s2 = LSNF_FRAG3_FLOATS * WT * HT, s3 = LSNF_FRAG3_FLOATS * WT * WT;
+            if (r < s1) { stage = 1; KT = NZT; }
+            else if ((r -= s1) < s2) { stage = 2; KT = HT; }
+            else if ((r -= s2) < s3) { stage = 3; KT = WT; }
+            else { r -= s3; stage = 4; KT = WT; }
+            frag3_decode(r, KT, &k0, &k1, &n, &part);
+            dst[q] = bf16_part_bits(fwd_mat(g, P, stage, k0, n), part) | (bf16_part_bits(fwd_mat(g, P, stage, k1, n), part) << 16);
+        }
     }
 }
 
@@ -331,7 +369,7 @@ hipError_t lsnf_launch_prepare(const LsnfGeo& g, const float* const* params_host
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int per_block = g.fwd_const_floats + g.fwd_block_floats + g.inv_const_floats + g.inv_block_floats +
-                          g.bwd_block_floats + g.nz * g.nz;
+                          g.bwd_block_floats + g.nz * g.nz + g.f3_block_floats;
     int gx = (per_block + 255) / 256;
     if (gx > 512) gx = 512;
     hipLaunchKernelGGL(lsnf_pack_kernel, dim3(gx, g.depth), dim3(256), 0, stream, pp, g, (const double*)scratch, plan);

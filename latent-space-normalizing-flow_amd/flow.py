@@ -162,6 +162,15 @@ def set_small_batch_max(rows: int) -> int:
     return _lib.load().lsnf_set_small_batch_max(int(rows))
 
 
+MATH_FP32, MATH_BF16X3 = 0, 1
+
+
+def set_math_mode(mode: int) -> int:
+    """Arithmetic of the throughput forward's GEMMs: MATH_FP32 (fp32 MFMA) or MATH_BF16X3 (error-free three-way bf16
+    split on the bf16 matrix pipe, fp32-class accuracy).  Returns the previous mode (mode < 0: query)."""
+    return _lib.load().lsnf_set_math_mode(int(mode))
+
+
 def new_act_saved(plan: "FlowPlan", B: int, device) -> torch.Tensor:
     """Uninitialised activation stash for `forward(..., act_saved=)` on a batch of B rows."""
     n = _lib.load().lsnf_act_saved_floats(plan.nz, plan.width, plan.depth, int(B))
