@@ -59,6 +59,13 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
 // registers 8*s .. 8*s+7 of an activation tile -> x1, x2, x3 of k-step s
 __device__ __forceinline__ void split_kstep(const f32x16& x, int s, Split3& out) {
     u32x4 w[3];
+#ifdef LSNF_ABLATE_SPLIT   // timing diagnostic only (wrong numbers): prices the VALU work of the operand split
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const unsigned u = __builtin_bit_cast(unsigned, x[8 * s + 2 * q]); w[0][q] = u; w[1][q] = u; w[2][q] = u; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out.p[i] = __builtin_bit_cast(bf16x8, w[i]);
+    return;
+#endif
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float a = x[8 * s + 2 * q], b = x[8 * s + 2 * q + 1];
@@ -106,36 +113,47 @@ __device__ __forceinline__ constexpr int first_kib(int NT, int KT) { return 6 * 
 // the six kept terms (weight part, activation part), smallest first
 #define LSNF_F3_TERMS(M) M(2, 0) M(0, 2) M(1, 1) M(1, 0) M(0, 1) M(0, 0)
 
-// two n-tiles x KT k-tiles: acc0/acc1 += W^T in.  Per k-step 6 fragment reads (3 parts x 2 tiles) feed 12 MFMAs;
-// the next k-step's reads are issued before the current MFMAs (second register set).
-template <int KT, bool PAIR>
+// NTILES (1 or 2) n-tiles x KT k-tiles out of one LDS buffer: acc_t += W_t^T in.  Per k-step 3 fragment reads (the
+// three weight parts) feed 6 MFMAs; the next k-step's reads -- across the tile boundary too, the second tile's panel
+// follows the first one's -- are issued before the current MFMAs (second register set), so a pair pays one pipeline
+// fill.  One dependent chain is enough: the 8-pass bf16 MFMA issues back to back on its own accumulator
+// (tools/micro/mfma_bf16.hip).
+template <int KT, int NTILES>
 __device__ __forceinline__ void panel_mma3(f32x16& acc0, f32x16& acc1, const Split3* in, const float* lbuf, int lane) {
     const bf16x8* wp = reinterpret_cast<const bf16x8*>(lbuf) + lane;
-    constexpr int T1 = KT * 6 * 64;                           // 16-byte offset of tile 1's panel
-    constexpr int NR = PAIR ? 6 : 3;
+    constexpr int STEPS = 2 * KT * NTILES;
     __builtin_amdgcn_sched_barrier(0);
-    bf16x8 a[3], b[3];
+    bf16x8 a[3];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) { a[p] = wp[p * 64]; b[p] = PAIR ? wp[T1 + p * 64] : a[p]; }
-    __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+    for (int p = 0; p < 3; ++p) a[p] = wp[p * 64];
+    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
 #pragma unroll
-    for (int ks = 0; ks < 2 * KT; ++ks) {
-        bf16x8 na[3], nb[3];
+    for (int idx = 0; idx < STEPS; ++idx) {
+        const int ks = idx % (2 * KT);
+        bf16x8 na[3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) { na[p] = a[p]; nb[p] = b[p]; }
-        if (ks + 1 < 2 * KT) {
+        for (int p = 0; p < 3; ++p) na[p] = a[p];
+        if (idx + 1 < STEPS) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) { na[p] = wp[((ks + 1) * 3 + p) * 64]; if (PAIR) nb[p] = wp[T1 + ((ks + 1) * 3 + p) * 64]; }
+            for (int p = 0; p < 3; ++p) na[p] = wp[((idx + 1) * 3 + p) * 64];
         }
-#define LSNF_F3_MMA(WI, XI)                                                                              \
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[WI], in[ks].p[XI], acc0, 0, 0, 0);             \
-        if (PAIR) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[WI], in[ks].p[XI], acc1, 0, 0, 0);
+#ifdef LSNF_ABLATE_MFMA    // timing diagnostic only (wrong numbers): everything but the matrix pipe (one MFMA per k-step kept)
+#define LSNF_F3_MMA(WI, XI) if (WI == 0 && XI == 0) { if (idx < 2 * KT) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], in[ks].p[0], acc0, 0, 0, 0); else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], in[ks].p[0], acc1, 0, 0, 0); }
+#else
+#define LSNF_F3_MMA(WI, XI)                                                                                 \
+        if (idx < 2 * KT) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[WI], in[ks].p[XI], acc0, 0, 0, 0); \
+        else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[WI], in[ks].p[XI], acc1, 0, 0, 0);
+#endif
         LSNF_F3_TERMS(LSNF_F3_MMA)
 #undef LSNF_F3_MMA
-        if (ks + 1 < 2 * KT) __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, PAIR ? 12 : 6, 0);
+        if (idx + 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#ifdef LSNF_ABLATE_MFMA
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#else
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+#endif
 #pragma unroll
-        for (int p = 0; p < 3; ++p) { a[p] = na[p]; b[p] = nb[p]; }
+        for (int p = 0; p < 3; ++p) a[p] = na[p];
     }
 }
 
@@ -156,10 +174,10 @@ __device__ __forceinline__ void gemm_stage3(Pipe3& pipe, const float* gsrc, cons
         out[t0] = init(t0);
         if constexpr (cnt == 2) {
             out[t0 + 1] = init(t0 + 1);
-            panel_mma3<KT, true>(out[t0], out[t0 + 1], in, lb, pipe.lane);
+            panel_mma3<KT, 2>(out[t0], out[t0 + 1], in, lb, pipe.lane);
             out[t0 + 1] = post(out[t0 + 1], t0 + 1);
         } else {
-            panel_mma3<KT, false>(out[t0], out[t0], in, lb, pipe.lane);
+            panel_mma3<KT, 1>(out[t0], out[t0], in, lb, pipe.lane);
         }
         out[t0] = post(out[t0], t0);
     });
@@ -187,8 +205,16 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3_kernel(const Fwd3A
     const long row = live ? sample : (long)a.B - 1;
 
     f32x16 x[NZT];
+#ifdef LSNF_ABLATE_IO    // timing diagnostic only: no HBM reads of z
+#pragma unroll
+    for (int t = 0; t < NZT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[t][r] = 0.001f * (float)(lane + r + t);
+    float ell = 0.0f;
+#else
     lsnf_load_rows<HT>(x, a.z_in, row, a.nz, a.half, h, a.vec4);
     float ell = a.objective ? a.objective[row] : 0.0f;
+#endif
 
     const LsnfActLayout al = lsnf_act_layout(a.B, HT, WT);
     const size_t wtile = (size_t)blockIdx.x * F3_WAVES + wave;
@@ -261,7 +287,11 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3_kernel(const Fwd3A
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float sig, l2;
+#ifdef LSNF_ABLATE_EPILOGUE
+                sig = tp[HT + t][r] * 0.25f + 0.5f; l2 = tp[HT + t][r];
+#else
                 lsnf_sigmoid_log2(tp[HT + t][r], sig, l2);
+#endif
                 x[HT + t][r] = (v[HT + t][r] + tp[t][r]) * sig;
                 sg[r] = sig;
                 lsum += l2;
@@ -280,6 +310,9 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3_kernel(const Fwd3A
 #pragma unroll
         for (int r = 0; r < 16; ++r) ss += x[t][r] * x[t][r];
     ss = lsnf_pair_sum(ss);
+#ifdef LSNF_ABLATE_IO
+    if (ss != 123.456f) return;   // keeps the computation alive, stores (practically) never happen
+#endif
     if (live) {
         float* zo = a.z_out + sample * (long)a.nz;
 #pragma unroll

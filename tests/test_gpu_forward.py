@@ -96,8 +96,9 @@ def test_forward_vs_oracle_ragged(lsnf, kernels, gpu_device, nz, width, B):
     assert (z1.cpu() - z1r).abs().max().item() <= Z_ABS * max(1.0, z1r.abs().max().item())
 
 
-def test_full_size_properties(lsnf, gpu_device):
-    """BASELINE.json's full size (nz=128, w=64, B=65536): size-independent properties.
+@pytest.mark.parametrize("math", ["fp32", "bf16x3"])
+def test_full_size_properties(lsnf, gpu_device, math):
+    """BASELINE.json's full size (nz=128, w=64, B=65536), both arithmetic modes: size-independent properties.
     (a) row independence: the first 4096 rows of the big launch equal a 4096-row launch bit for bit;
     (b) a strided sample of rows equals the oracle within tolerance;
     (c) objective is additive: forward(z, obj) == forward(z, 0) + obj."""
@@ -107,6 +108,7 @@ def test_full_size_properties(lsnf, gpu_device):
     z = torch.randn(B, nz, generator=torch.Generator().manual_seed(1234))
     zd = z.to(gpu_device)
     prev = lsnf.flow.set_small_batch_max(8192)
+    prev_math = lsnf.flow.set_math_mode(lsnf.flow.MATH_BF16X3 if math == "bf16x3" else lsnf.flow.MATH_FP32)
     z1, ld, ll, _ = lsnf.forward(plan, zd)                                   # throughput kernel
     z1s, lds, lls, _ = lsnf.forward(plan, zd[:16384].contiguous())           # throughput kernel, fewer rows
     assert torch.equal(z1[:16384], z1s) and torch.equal(ll[:16384], lls) and torch.equal(ld[:16384], lds)
@@ -123,6 +125,28 @@ def test_full_size_properties(lsnf, gpu_device):
     _, ld2, _, _ = lsnf.forward(plan, zd, obj)
     assert (ld2 - (ld + 3.25)).abs().max().item() <= 2e-5
     assert torch.isfinite(ll).all()
+    lsnf.flow.set_math_mode(prev_math)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_split_bf16_is_fp32_faithful(lsnf, gpu_device, name):
+    """The error-free three-way bf16 split (lsnf_fwd3.hip) is not a reduced-precision mode: against a float64
+    evaluation of the oracle its log-prob error is of the size of the fp32-MFMA kernel's own (both ~3e-7 relative,
+    the reference's fp32 noise floor), on every fixture incl. the trained-like ones."""
+    p, g = load_golden(name)
+    plan = _plan(lsnf, p, g, gpu_device)[0]
+    z = torch.from_numpy(g["z"])
+    _, _, ll64 = O.flow_log_prob(O.to_dtype(p, torch.float64), z.double())
+    prev = lsnf.flow.set_small_batch_max(0)
+    err = {}
+    for mode, tag in ((lsnf.flow.MATH_FP32, "fp32"), (lsnf.flow.MATH_BF16X3, "bf16x3")):
+        prev_math = lsnf.flow.set_math_mode(mode)
+        _, _, ll, _ = lsnf.forward(plan, z.to(gpu_device))
+        lsnf.flow.set_math_mode(prev_math)
+        err[tag] = ((ll.cpu().double() - ll64).abs() / ll64.abs().clamp_min(1.0)).max().item()
+    lsnf.flow.set_small_batch_max(prev)
+    assert err["fp32"] <= 2e-6 and err["bf16x3"] <= 2e-6, err
+    assert err["bf16x3"] <= 2.0 * err["fp32"] + 1e-7, err
 
 
 def test_errors_are_loud(lsnf, gpu_device):
