@@ -32,6 +32,8 @@ B_PER_GPU = 65536
 FLOP_PER_SAMPLE = DEPTH * (2 * NZ * NZ + 2 * (NZ // 2 * WIDTH + WIDTH * WIDTH + WIDTH * NZ))  # 327 680
 BYTES_PER_SAMPLE_FUSED = 8 * NZ + 8                                                            # 1 032 (whole stack fused)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # MI355X_MICROARCH.md: "~2.5 PF dense" = 16 x the fp32 matrix rate (same table)
+SPLIT_MFMA_PER_PRODUCT = 6      # bf16x3 mode: six bf16 MFMAs of K=16 carry one fp32-accurate 32x32x16 product
 PEAK_HBM_GBS = 8000.0
 
 
@@ -99,6 +101,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank logic on a box with fewer GPUs than ranks)")
+    ap.add_argument("--math", choices=["bf16x3", "fp32"], default="bf16x3",
+                    help="arithmetic of the forward's GEMMs: bf16x3 = error-free three-way bf16 split on the bf16 matrix "
+                         "pipe (fp32-class accuracy, the library default); fp32 = fp32 MFMA")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the independent steps alternate over (2: the head of step i+1 overlaps the tail of step i)")
     args = ap.parse_args()
@@ -121,6 +126,8 @@ def main():
             dist.init_process_group(args.backend)
 
     import lsnf_amd
+    MATH = {"fp32": lsnf_amd.flow.MATH_FP32, "bf16x3": lsnf_amd.flow.MATH_BF16X3}
+    lsnf_amd.flow.set_math_mode(MATH[args.math])
     weights = synth_weights(1)
     plan = lsnf_amd.prepare([w.to(dev) for w in weights], NZ, WIDTH, DEPTH)
     z = torch.randn(B_PER_GPU, NZ, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
@@ -180,17 +187,24 @@ def main():
         elapsed = t.item()
 
     # kernel-only loop for the roofline: HIP events on the launch stream around K back-to-back launches
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for _ in range(5):
-        lsnf_amd.forward(plan, z, out=(z1, logdet, ll))
-    torch.cuda.synchronize()
-    kl = max(20, min(args.steps, 200))
-    e0.record()
-    for _ in range(kl):
-        lsnf_amd.forward(plan, z, out=(z1, logdet, ll))
-    e1.record()
-    torch.cuda.synchronize()
-    kern_ms = e0.elapsed_time(e1) / kl
+    def kernel_ms(mode):
+        lsnf_amd.flow.set_math_mode(MATH[mode])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            lsnf_amd.forward(plan, z, out=(z1, logdet, ll))
+        torch.cuda.synchronize()
+        kl = max(20, min(args.steps, 200))
+        e0.record()
+        for _ in range(kl):
+            lsnf_amd.forward(plan, z, out=(z1, logdet, ll))
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / kl
+    other = "fp32" if args.math == "bf16x3" else "bf16x3"
+    kern_ms_other = kernel_ms(other)          # the other arithmetic mode, reported beside the measured one
+    ll_other = ll.clone()
+    kern_ms = kernel_ms(args.math)            # also leaves the library in the measured mode
+    ll_rel_between_modes = ((ll - ll_other).abs() / ll.abs().clamp_min(1.0)).max().item()
     # prepare (weight folding + fp64 Gauss-Jordan), amortised over the Langevin loop in production
     p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     wd = [w.to(dev) for w in weights]
@@ -204,30 +218,42 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B_PER_GPU * args.steps / elapsed
-        tflops = FLOP_PER_SAMPLE * B_PER_GPU / (kern_ms * 1e-3) / 1e12
+        tflops = FLOP_PER_SAMPLE * B_PER_GPU / (kern_ms * 1e-3) / 1e12          # algorithmic (fp32-equivalent) rate
+        if args.math == "bf16x3":   # the matrix pipe executes 6 bf16 MFMA flops per algorithmic flop: price THAT against the bf16 peak
+            rl = {"bound": "mfma", "achieved": SPLIT_MFMA_PER_PRODUCT * tflops, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                  "frac": SPLIT_MFMA_PER_PRODUCT * tflops / PEAK_BF16_MFMA_TFLOPS, "kernel": "lsnf_fwd3_kernel<Fwd3Cfg<2,2>>",
+                  "note": "executed bf16 MFMA flops (6 per algorithmic flop) vs the dense bf16 peak; algorithmic_tflops is "
+                          "the fp32-equivalent rate, 1.0 of the fp32 MFMA peak would be 157.3"}
+        else:
+            rl = {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                  "frac": tflops / PEAK_FP32_MFMA_TFLOPS, "kernel": "lsnf_fwd_kernel<FwdCfg<2,2>, 8>"}
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+                traffic = (json.load(open(tfile)).get(args.math) or {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
             "metric": "latent-samples/sec through flow+logdet, nz=128 B=65536",
             "value": value, "unit": "latent-samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16x3" if args.math == "bf16x3" else "f32", "data": "synthetic",
             "config": {"workload": "CIFAR-10 flow prior nz=128 f_width=64 f_depth=5 affine, forward+logdet+log-prob, "
                                    "B=65536 synthetic z per GPU (BASELINE.json configs[2])",
                        "rows_per_gpu": B_PER_GPU, "global_rows": world * B_PER_GPU,
                        "parallelism": f"dp{world} (rows sharded, one all-reduce of sum ll)" if world > 1 else "single GPU",
                        "streams": n_streams, "clock_ramp_launches_before_warmup": RAMP_LAUNCHES,
-                       "prepare_ms_not_in_step": prep_ms},
-            "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel": "lsnf_fwd_kernel<FwdCfg<2,2>, 8>", "kernel_ms": kern_ms,
-                         "flop_per_launch": FLOP_PER_SAMPLE * B_PER_GPU,
-                         "hbm_frac_secondary": BYTES_PER_SAMPLE_FUSED * B_PER_GPU / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+                       "prepare_ms_not_in_step": prep_ms,
+                       "math": ("bf16x3: every GEMM operand split error-free into three bf16 terms, six bf16 MFMAs per product, "
+                                "fp32 accumulation; log-prob error vs float64 equals the fp32-MFMA kernel's (tests/"
+                                "test_gpu_forward.py::test_split_bf16_is_fp32_faithful)") if args.math == "bf16x3" else "fp32 MFMA",
+                       "other_math_mode": {"math": other, "kernel_ms": kern_ms_other,
+                                           "samples_per_s_kernel_only": B_PER_GPU / (kern_ms_other * 1e-3),
+                                           "max_rel_ll_difference_between_modes": ll_rel_between_modes}},
+            "roofline": dict(rl, traffic=traffic, kernel_ms=kern_ms, flop_per_launch=FLOP_PER_SAMPLE * B_PER_GPU,
+                             algorithmic_tflops=tflops, fp32_mfma_peak=PEAK_FP32_MFMA_TFLOPS,
+                             hbm_frac_secondary=BYTES_PER_SAMPLE_FUSED * B_PER_GPU / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(weights)

@@ -56,7 +56,7 @@ def main():
     step_size, sigma, nc, B = 0.1, 0.3, 3, args.batch
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dev = torch.device("cuda", local_rank)
+    dev = parallel.pick_device()                                # GPU of LOCAL_RANK (replaces get_free_gpu / nvidia-smi, train.py:708-714)
     torch.cuda.set_device(dev)
     rank, world, _ = parallel.init_from_env(dev)
     torch.manual_seed(1); np.random.seed(1)                     # same initial weights on every rank
@@ -72,19 +72,23 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(100 + rank)   # every rank owns different rows
     x = torch.tanh(torch.randn(B, nc, size, size, device=dev, generator=gen))
 
+    it = [0]
+
     def iteration():
         z0 = torch.randn(B, nz, 1, 1, device=dev, generator=gen)
         gmod = netG.module if world > 1 else netG               # Langevin needs d/dz only: no gradient sync
+        # Langevin noise drawn inside the update kernel: one Philox stream for the whole job, keyed by the GLOBAL row
+        # (row0 = rank*B) and the global step count, so the draws do not depend on how the rows are sharded
+        noise = lsnf_amd.flow.PhiloxNoise(seed=1234, offset=it[0] * K, row0=rank * B)
+        it[0] += 1
         zk, ggn, gfn, f = langevin.sample_langevin_post_z_with_flow(z0, x, gmod, netF, g_l_steps=K, g_l_step_size=step_size,
-                                                                    g_llhd_sigma=sigma, g_l_with_noise=True, generator=gen)
+                                                                    g_llhd_sigma=sigma, g_l_with_noise=True, philox=noise)
         optG.zero_grad()
         loss_g = mse(netG(zk), x) / B                           # train.py:391-393 (DDP averages the gradients)
         loss_g.backward()
         optG.step()
-        optF.zero_grad()                                        # train.py:404-415 with the one-bucket all-reduce
-        z1, logdet, _ = netF(zk.view(B, nz), objective=torch.zeros(B, device=dev))
-        loss_f = -(-0.5 * (z1 ** 2).sum(1) + float(np.log(2 * np.pi)) + logdet).mean()
-        loss_f.backward()
+        optF.zero_grad(set_to_none=True)                        # train.py:404-415, fused: loss and the 60 gradients in 5 launches,
+        loss_f = netF.mle_grads(zk.view(B, nz))                 # then the one-bucket all-reduce
         parallel.allreduce_gradients(netF.parameters(), average=True)
         torch.nn.utils.clip_grad_norm_(netF.parameters(), 100.0)
         optF.step()
@@ -102,7 +106,7 @@ def main():
     z2d = torch.randn(B, nz, device=dev); gg = torch.randn(B, nz, device=dev); nn_ = torch.randn(B, nz, device=dev)
     ms_flow, _ = wall(lambda: netF.langevin_step(z2d, gg, nn_, step_size), 200)
     zk = torch.randn(B, nz, 1, 1, device=dev)
-    ms_mle, _ = wall(lambda: langevin.flow_mle_step(netF, optF, zk, f_max_norm=100.0), 20)
+    ms_mle, _ = wall(lambda: langevin.flow_mle_step(netF, optF, zk, f_max_norm=100.0, fused=True), 20)
     if world > 1:
         t = torch.tensor([ms_iter], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

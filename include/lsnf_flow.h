@@ -73,7 +73,7 @@ int lsnf_set_small_batch_max(int rows);
  * variable "fp32" / "bf16x3"). */
 #define LSNF_MATH_FP32 0
 #define LSNF_MATH_BF16X3 1
-#define LSNF_MATH_DEFAULT LSNF_MATH_FP32
+#define LSNF_MATH_DEFAULT LSNF_MATH_BF16X3
 int lsnf_set_math_mode(int mode);
 
 /* Device query: writes the gfx arch name (e.g. "gfx950") of device `device`; LSNF_E_NODEVICE

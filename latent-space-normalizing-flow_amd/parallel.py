@@ -30,6 +30,22 @@ def init_from_env(device: Optional[torch.device] = None, backend: Optional[str] 
     return rank, world, local_rank
 
 
+def pick_device(prefer_free: bool = True) -> torch.device:
+    """Device for this process -- replaces the reference's `get_free_gpu()` (train.py:708-714), which shells out to
+    `nvidia-smi`.  Under torch.distributed.run: the GPU of LOCAL_RANK (one process per GPU).  Standalone: the
+    visible GPU with the most free memory (`torch.cuda.mem_get_info`, no external tool), or GPU 0 if
+    `prefer_free` is False.  Raises if no GPU is visible: the flow has no CPU path."""
+    n = torch.cuda.device_count()
+    if n == 0:
+        raise RuntimeError("no ROCm GPU visible: the flow prior has no CPU path")
+    if "LOCAL_RANK" in os.environ:
+        return torch.device("cuda", int(os.environ["LOCAL_RANK"]) % n)
+    if not prefer_free or n == 1:
+        return torch.device("cuda", 0)
+    free = [torch.cuda.mem_get_info(i)[0] for i in range(n)]
+    return torch.device("cuda", max(range(n), key=lambda i: free[i]))
+
+
 def shard_bounds(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
     """Contiguous slab [start, stop) of `n_rows` owned by `rank`; slab sizes differ by at most one row."""
     if not (0 <= rank < world):

@@ -101,3 +101,20 @@ def test_geometry_queries_need_no_gpu():
     assert lib.lsnf_plan_floats(128, 64, 17, 1) == 0
     assert lib.lsnf_plan_floats(128, 64, 5, 0) == lib.lsnf_plan_floats(128, 64, 5, 1) and lib.lsnf_plan_floats(128, 64, 5, 2) == 0
     assert lib.lsnf_backward_params_workspace_floats(128, 64, 5, 100) > 0
+
+
+def test_pick_device_without_gpu_is_loud(monkeypatch):
+    """parallel.pick_device replaces get_free_gpu (train.py:708-714, nvidia-smi): LOCAL_RANK decides under
+    torch.distributed.run; with no GPU it raises instead of handing back a CPU device."""
+    import torch
+    from lsnf_amd import parallel
+    if torch.cuda.device_count() == 0:
+        with pytest.raises(RuntimeError):
+            parallel.pick_device()
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    monkeypatch.setenv("LOCAL_RANK", "6")
+    assert parallel.pick_device() == torch.device("cuda", 2)
+    monkeypatch.delenv("LOCAL_RANK")
+    assert parallel.pick_device(prefer_free=False) == torch.device("cuda", 0)
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda i: ((10, 50, 30, 20)[i], 100))
+    assert parallel.pick_device() == torch.device("cuda", 1)

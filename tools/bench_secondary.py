@@ -38,6 +38,11 @@ for (tag, nz, w, B) in [("C2/C4 SVHN/CelebA nz=100 w=64 B=100", 100, 64, 100), (
     n = 200 if B <= 1000 else 30
     r = {"config": tag, "B": B}
     r["forward_logprob_us"] = timeit(lambda: lsnf_amd.forward(plan, z), n)
+    if B > 16384:
+        pm = lsnf_amd.flow.set_math_mode(1 - lsnf_amd.flow.set_math_mode(-1))
+        r["forward_logprob_other_math_mode_us"] = timeit(lambda: lsnf_amd.forward(plan, z), n)
+        r["default_math_mode"] = "bf16x3" if pm == 1 else "fp32"
+        lsnf_amd.flow.set_math_mode(pm)
     z1, ld, ll, saved = lsnf_amd.forward(plan, z, save_for_backward=True)
     r["forward_saving_us"] = timeit(lambda: lsnf_amd.forward(plan, z, save_for_backward=True), n)
     r["backward_z_us"] = timeit(lambda: lsnf_amd.backward_z(plan, z1, saved, ll_scale=-1.0), n)
