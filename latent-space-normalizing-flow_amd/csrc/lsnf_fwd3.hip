@@ -47,7 +47,18 @@ struct Fwd3Args {
     float* z_out; float* logdet_out; float* ll_out; float* z_saved; float* act_saved;
     int B, nz, half, n_blocks, vec4;
     double* stats;
+    unsigned long long* stamps;        // LSNF_STAMPS diagnostic build only: [waves & 2047][64] clock stamps
 };
+
+#ifdef LSNF_STAMPS   // in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz (tools/stamps_fwd3.py)
+#define F3_STAMP(i, INSN)                                                                               \
+    do { __builtin_amdgcn_sched_barrier(0);                                                             \
+         unsigned long long t_; asm volatile(INSN " %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");  \
+         __builtin_amdgcn_sched_barrier(0);                                                             \
+         if (a.stamps && lane == 0) a.stamps[(((size_t)blockIdx.x * F3_WAVES + wave) & 2047) * 64 + (i)] = t_; } while (0)
+#else
+#define F3_STAMP(i, INSN) do {} while (0)
+#endif
 
 // the three bf16 terms of one k-step (16 features of one 32-sample tile), B-operand order
 struct Split3 { bf16x8 p[3]; };
@@ -117,7 +128,8 @@ __device__ __forceinline__ constexpr int first_kib(int NT, int KT) { return 6 * 
 // three weight parts) feed 6 MFMAs; the next k-step's reads -- across the tile boundary too, the second tile's panel
 // follows the first one's -- are issued before the current MFMAs (second register set), so a pair pays one pipeline
 // fill.  One dependent chain is enough: the 8-pass bf16 MFMA issues back to back on its own accumulator
-// (tools/micro/mfma_bf16.hip).
+// (tools/micro/mfma_bf16.hip).  Measured and rejected (A/B in one job, tools/ablate_fwd3.sh): reads two k-steps ahead
+// (+2 us), bias loads before the acquire barrier (+1 us), two interleaved accumulator chains (+5 us, spills).
 template <int KT, int NTILES>
 __device__ __forceinline__ void panel_mma3(f32x16& acc0, f32x16& acc1, const Split3* in, const float* lbuf, int lane) {
     const bf16x8* wp = reinterpret_cast<const bf16x8*>(lbuf) + lane;
@@ -172,8 +184,8 @@ __device__ __forceinline__ void gemm_stage3(Pipe3& pipe, const float* gsrc, cons
             lb = pipe.template acquire<NEXT_KIB>(gnext);
         }
         out[t0] = init(t0);
+        if constexpr (cnt == 2) out[t0 + 1] = init(t0 + 1);
         if constexpr (cnt == 2) {
-            out[t0 + 1] = init(t0 + 1);
             panel_mma3<KT, 2>(out[t0], out[t0 + 1], in, lb, pipe.lane);
             out[t0 + 1] = post(out[t0 + 1], t0 + 1);
         } else {
@@ -195,6 +207,8 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3_kernel(const Fwd3A
     const int lane = tid & 63;
     const int m = lane & 31, h = lane >> 5;
 
+    F3_STAMP(0, "s_memtime");
+    F3_STAMP(50, "s_memrealtime");
     Pipe3 pipe;
     pipe.buf0 = buf0; pipe.slot = C::SLOT3; pipe.wave = wave; pipe.lane = lane;
     pipe.template prime<first_kib(C::P1, C::KT1)>(a.panels3);
@@ -338,6 +352,8 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3_kernel(const Fwd3A
             lsnf_publish_stats(a.stats, tl, td, a.B);
         }
     }
+    F3_STAMP(41, "s_memtime");
+    F3_STAMP(51, "s_memrealtime");
 }
 
 template <class C>
@@ -365,6 +381,12 @@ hipError_t lsnf_launch_forward3(const LsnfGeo& g, const float* plan, int first_b
     a.panels3 = plan + g.off_f3_panels + (size_t)first_block * g.f3_block_floats;
     a.z_in = z_in; a.objective = objective; a.z_out = z_out; a.logdet_out = logdet_out; a.ll_out = ll_out;
     a.z_saved = z_saved; a.B = B; a.nz = g.nz; a.half = g.half; a.n_blocks = n_blocks; a.vec4 = vec4;
+    a.stamps = nullptr;
+#ifdef LSNF_STAMPS
+    { extern unsigned long long* g_lsnf_stamps;
+      if (!g_lsnf_stamps) { if (hipMalloc(&g_lsnf_stamps, sizeof(unsigned long long) * 64 * 4 * 4096) != hipSuccess) g_lsnf_stamps = nullptr; }
+      a.stamps = g_lsnf_stamps; }
+#endif
     if (g.HT == 1 && g.WT == 1) return launch_fwd3<Fwd3Cfg<1, 1>>(a, stream);
     if (g.HT == 2 && g.WT == 2) return launch_fwd3<Fwd3Cfg<2, 2>>(a, stream);
     if (g.HT == 2 && g.WT == 4) return launch_fwd3<Fwd3Cfg<2, 4>>(a, stream);

@@ -4,9 +4,11 @@
 set -e
 cd "$(dirname "$0")/../latent-space-normalizing-flow_amd/csrc"
 mkdir -p ../_ablate
-for v in "base:" "nosplit:-DLSNF_ABLATE_SPLIT" "nomfma:-DLSNF_ABLATE_MFMA" "noio:-DLSNF_ABLATE_IO" "nodma:-DLSNF_ABLATE_DMA" \
-         "nobar:-DLSNF_ABLATE_BARRIER" "noepi:-DLSNF_ABLATE_EPILOGUE" "nosplit_noepi:-DLSNF_ABLATE_SPLIT -DLSNF_ABLATE_EPILOGUE" \
-         "mfmaonly:-DLSNF_ABLATE_SPLIT -DLSNF_ABLATE_EPILOGUE -DLSNF_ABLATE_IO -DLSNF_ABLATE_DMA -DLSNF_ABLATE_BARRIER"; do
+if [ $# -eq 0 ]; then
+  set -- "base:" "nosplit:-DLSNF_ABLATE_SPLIT" "noio:-DLSNF_ABLATE_IO" "noepi:-DLSNF_ABLATE_EPILOGUE" \
+         "mfmaonly:-DLSNF_ABLATE_SPLIT -DLSNF_ABLATE_EPILOGUE -DLSNF_ABLATE_IO -DLSNF_ABLATE_DMA -DLSNF_ABLATE_BARRIER"
+fi
+for v in "$@"; do
   name=${v%%:*}; flags=${v#*:}
   make -j8 BUILD=_build_f3_$name OUT=../_ablate/f3_$name.so EXTRA="$flags" > /dev/null
   echo built $name
