@@ -143,7 +143,10 @@ def main():
     outs = [(torch.empty_like(z), torch.empty(B_PER_GPU, device=dev), torch.empty(B_PER_GPU, device=dev))
             for _ in range(n_streams)]
     z1, logdet, ll = outs[0]
-    reducers = [parallel.PipelinedStatsReducer(dev) for _ in range(n_streams)]
+    # one collective per REDUCE_BUCKET evaluations of a stream (each evaluation's sums travel, bucketed): the forward
+    # kernels fill the chip exactly (one workgroup per CU), so every collective kernel delays one of their workgroups
+    REDUCE_BUCKET = 8
+    reducers = [parallel.PipelinedStatsReducer(dev, bucket=REDUCE_BUCKET) for _ in range(n_streams)]
     counter = [0]
     torch.cuda.synchronize()
 
@@ -242,7 +245,8 @@ def main():
             "config": {"workload": "CIFAR-10 flow prior nz=128 f_width=64 f_depth=5 affine, forward+logdet+log-prob, "
                                    "B=65536 synthetic z per GPU (BASELINE.json configs[2])",
                        "rows_per_gpu": B_PER_GPU, "global_rows": world * B_PER_GPU,
-                       "parallelism": f"dp{world} (rows sharded, one all-reduce of sum ll)" if world > 1 else "single GPU",
+                       "parallelism": (f"dp{world} (rows sharded; sum ll / sum logdet / rows of every evaluation all-reduced, "
+                                       f"{REDUCE_BUCKET} evaluations per collective)") if world > 1 else "single GPU",
                        "streams": n_streams, "clock_ramp_launches_before_warmup": RAMP_LAUNCHES,
                        "prepare_ms_not_in_step": prep_ms,
                        "math": ("bf16x3: every GEMM operand split error-free into three bf16 terms, six bf16 MFMAs per product, "

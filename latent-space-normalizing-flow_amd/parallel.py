@@ -86,54 +86,75 @@ def reduce_stats_inplace(stats: torch.Tensor, group=None) -> torch.Tensor:
 
 
 class PipelinedStatsReducer:
-    """Hides the latency of the one collective of the path behind the next evaluation.
+    """Hides the one collective of the path behind the following evaluations, and buckets it.
 
-    The all-reduce of [sum ll, sum logdet, rows] is ~20 us of pure latency on 8 GPUs (24 bytes); nothing in the
-    Langevin loop consumes the reduced value before the next flow evaluation starts (it is a logged diagnostic,
-    train.py:320,332), so step i's all-reduce runs on the communication stream WHILE step i+1's forward kernel
-    runs on the compute stream.  Two stats buffers alternate; a buffer is handed out again only after the
-    collective that reads it has been waited for (a stream-level wait for RCCL, no host sync).
+    The all-reduce of [sum ll, sum logdet, rows] is ~20 us of pure latency on 8 GPUs; nothing in the Langevin loop
+    consumes the reduced value before the next flow evaluation starts (it is a logged diagnostic, train.py:320,332).
+    So the sums of `bucket` consecutive evaluations are gathered in one bank (row j = the 8-double stats buffer of
+    evaluation j, filled by the forward kernel itself) and travel in ONE asynchronous all-reduce per bank, on the
+    communication stream, WHILE the next bank is being filled: every evaluation's sums are still reduced, but a
+    collective kernel competes with the forward kernels for a CU (they fill the chip exactly: one workgroup per CU) only
+    once per `bucket` evaluations.  Two banks alternate; a bank is handed out again only after the collective that
+    reads it has been waited for (a stream-level wait for RCCL, no host sync).  bucket = 1: one collective per
+    evaluation.
 
-        red = PipelinedStatsReducer(device)
+        red = PipelinedStatsReducer(device, bucket=8)
         for i in range(K):
-            stats = red.next_buffer()               # waits (stream-level) for the collective of step i-2
+            stats = red.next_buffer()               # row of the bank being filled
             flow.forward(plan, z, stats=stats)
-            red.submit(stats)                       # async all-reduce of stats[4:7]
-        totals = red.finish()                       # public part of the last submitted buffer, reduced
+            red.submit(stats)                       # every 8th call: async all-reduce of the bank
+        totals = red.finish()                       # [sum ll, sum logdet, rows] of the last evaluation, reduced
     """
 
-    def __init__(self, device, group=None, make_buffer=None):
-        mk = make_buffer or (lambda: torch.zeros(8, dtype=torch.float64, device=device))
-        self.bufs = [mk(), mk()]
+    def __init__(self, device, group=None, make_buffer=None, bucket: int = 1):
+        if bucket < 1:
+            raise ValueError("bucket must be >= 1")
+        mk = make_buffer or (lambda n: torch.zeros(n, 8, dtype=torch.float64, device=device))
+        self.bucket = bucket
+        self.banks = [mk(bucket), mk(bucket)]
         self.work = [None, None]
-        self.i = 0
+        self.bank = 0          # bank being filled
+        self.fill = 0          # rows of it handed out and submitted
         self.group = group
-        self.last = None
+        self.last = None       # (bank, row) of the last submitted evaluation
 
     def _multi(self):
         return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
 
     def next_buffer(self) -> torch.Tensor:
-        k = self.i & 1
-        if self.work[k] is not None:
-            self.work[k].wait()
-            self.work[k] = None
-        return self.bufs[k]
+        if self.fill == 0 and self.work[self.bank] is not None:     # first row of a bank whose collective may be in flight
+            self.work[self.bank].wait()
+            self.work[self.bank] = None
+        return self.banks[self.bank][self.fill]
+
+    def _flush(self) -> None:
+        if self.fill == 0:
+            return
+        if self._multi():
+            # the whole bank in one message: the kernel-internal slots 0..3 are zero at rest and stay zero; rows of a
+            # partly filled bank (finish() only) that were not written this time carry stale values nobody reads
+            self.work[self.bank] = dist.all_reduce(self.banks[self.bank], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.bank ^= 1
+        self.fill = 0
 
     def submit(self, stats: torch.Tensor) -> None:
-        k = self.i & 1
-        assert stats is self.bufs[k], "submit() must receive the buffer handed out by next_buffer()"
-        if self._multi():
-            self.work[k] = dist.all_reduce(stats[4:7], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self.last = k
-        self.i += 1
+        row = self.banks[self.bank][self.fill]
+        assert stats.data_ptr() == row.data_ptr(), "submit() must receive the buffer handed out by next_buffer()"
+        self.last = (self.bank, self.fill)
+        self.fill += 1
+        if self.fill == self.bucket:
+            self._flush()
 
     def finish(self) -> Optional[torch.Tensor]:
+        self._flush()                                 # a partly filled bank travels too
         for k in (0, 1):
             if self.work[k] is not None:
                 self.work[k].wait()
                 self.work[k] = None
-        return None if self.last is None else self.bufs[self.last][4:7]
+        if self.last is None:
+            return None
+        b, r = self.last
+        return self.banks[b][r][4:7]
 
 
 def sharded_log_prob(evaluate: Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]],

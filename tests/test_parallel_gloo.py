@@ -43,6 +43,14 @@ def _worker(rank, world, port, out):
         st[4], st[5], st[6] = float(ll.sum()) * (it + 1), float(ld.sum()), float(ll.numel())
         red.submit(st)
     fin = red.finish().clone()
+    # (1c) bucketed: the sums of 3 consecutive evaluations travel in one collective; 7 evaluations = 2 full banks + 1 row
+    red3 = P.PipelinedStatsReducer(torch.device("cpu"), bucket=3)
+    for it in range(7):
+        st = red3.next_buffer()
+        st[4], st[5], st[6] = float(ll.sum()) * (it + 1), float(ld.sum()), float(ll.numel())
+        red3.submit(st)
+    fin3 = red3.finish().clone()
+    bank1 = red3.banks[1][:, 4:7].clone()            # evaluations 3, 4, 5, reduced
     # (2) broadcast: rank 1 starts from different weights and must end up with rank 0's
     q = O.init_params(NZ, WIDTH, DEPTH, seed=4 + rank)
     live = [q[k] for k in sorted(q) if O.is_live_param(k)]
@@ -57,7 +65,7 @@ def _worker(rank, world, port, out):
     dead = torch.nn.Parameter(torch.zeros(3))            # a parameter without grad must be skipped
     n = P.allreduce_gradients(leaves + [dead], average=False)
     if rank == 0:
-        out.put({"stats": stats.tolist(), "same": same, "n": n, "piped": [p_.tolist() for p_ in piped], "fin": fin.tolist(), "ll": ll.tolist(), "lo_hi": (lo, hi),
+        out.put({"stats": stats.tolist(), "same": same, "n": n, "piped": [p_.tolist() for p_ in piped], "fin": fin.tolist(), "fin3": fin3.tolist(), "bank1": bank1.tolist(), "ll": ll.tolist(), "lo_hi": (lo, hi),
                  "grads": {k: l.grad.numpy().copy() for k, l in zip(keys, leaves)}})
     else:
         out.put({"same": same, "lo_hi": (lo, hi)})
@@ -106,6 +114,10 @@ def test_two_rank_gloo_matches_full_batch():
     for k, v in enumerate(r0["piped"]):                # steps 0,1,2 seen when their buffer is handed out again
         assert abs(v[0] - tot * (k + 1)) <= 1e-6 * abs(tot * (k + 1)) and v[2] == B
     assert abs(r0["fin"][0] - tot * 5) <= 1e-6 * abs(tot * 5) and r0["fin"][2] == B
+    # bucketed reducer: evaluation 6 (alone in its bank) and evaluations 3..5 (one collective)
+    assert abs(r0["fin3"][0] - tot * 7) <= 1e-6 * abs(tot * 7) and r0["fin3"][2] == B
+    for j, row in enumerate(r0["bank1"]):
+        assert abs(row[0] - tot * (4 + j)) <= 1e-6 * abs(tot * (4 + j)) and row[2] == B
     lo, hi = r0["lo_hi"]
     assert torch.allclose(torch.tensor(r0["ll"]), ll[lo:hi], rtol=1e-6, atol=1e-5)
     ref = O.grad_neg_mean_ll_wrt_params(p, z)
