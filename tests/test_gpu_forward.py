@@ -179,3 +179,31 @@ def test_in_kernel_batch_sums(lsnf, kernels, gpu_device, B):
         assert s[6].item() == B and s[0].item() == 0.0 and s[1].item() == 0.0 and s[2].item() == 0.0
     lsnf.forward(plan, torch.zeros(0, 128, device=gpu_device), stats=stats)
     assert stats.cpu()[4:7].tolist() == [0.0, 0.0, 0.0]
+
+
+@pytest.mark.parametrize("z_scale,w_scale", [(1e-3, 1.0), (1.0, 1.0), (30.0, 1.0), (3.0, 4.0), (1.0, 0.05)])
+def test_split_bf16_dynamic_range(lsnf, gpu_device, z_scale, w_scale):
+    """bf16 keeps fp32's exponent range, so the error-free split has no range to manage: tiny / huge latents and
+    re-scaled MLP weights (what training does to them) leave its error where the fp32-MFMA kernel's is, measured
+    against a float64 evaluation of the oracle."""
+    nz, width, depth, B = 128, 64, 5, 17000
+    p = O.init_params(nz, width, depth, seed=11, fcz_std=0.05)
+    g = torch.Generator().manual_seed(12)
+    for k in list(p):
+        if k.endswith("fc_1.w") or k.endswith("fc_2.w"):
+            p[k] = p[k] * w_scale
+        if k.endswith("actnorm.logs"):
+            p[k] = p[k] + 0.1 * torch.randn(p[k].shape, generator=g)
+    z = torch.randn(B, nz, generator=g) * z_scale
+    idx = torch.arange(0, B, 61)
+    _, _, ll64 = O.flow_log_prob(O.to_dtype(p, torch.float64), z[idx].double())
+    plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
+    err = {}
+    for mode, tag in ((lsnf.flow.MATH_FP32, "fp32"), (lsnf.flow.MATH_BF16X3, "bf16x3")):
+        prev = lsnf.flow.set_math_mode(mode)
+        _, _, ll, _ = lsnf.forward(plan, z.to(gpu_device))
+        lsnf.flow.set_math_mode(prev)
+        assert torch.isfinite(ll).all()
+        err[tag] = ((ll.cpu()[idx].double() - ll64).abs() / ll64.abs().clamp_min(1.0)).max().item()
+    assert err["fp32"] <= 1e-5 and err["bf16x3"] <= 1e-5, err
+    assert err["bf16x3"] <= 2.0 * err["fp32"] + 1e-7, err
