@@ -279,9 +279,10 @@ def langevin_step(plan: FlowPlan, z: torch.Tensor, grad_g: Optional[torch.Tensor
 def backward_params(plan: FlowPlan, params: Sequence[torch.Tensor], z_in: torch.Tensor, z_out: torch.Tensor,
                     z_saved: Optional[torch.Tensor], g_z1: Optional[torch.Tensor] = None,
                     g_logdet: Optional[torch.Tensor] = None, ll_scale: Optional[float] = None,
-                    want_grad_z: bool = False):
+                    want_grad_z: bool = False, want_flat: bool = False):
     """dL/dtheta for the depth*12 live tensors (train.py:406-411).  Returns a list of gradients shaped like
-    `params` (and dL/dz_in as a second value if want_grad_z)."""
+    `params` (and dL/dz_in as a second value if want_grad_z; and, last, the ONE flat buffer the gradients are views
+    of if want_flat -- a global norm / clip is then one reduction instead of 60)."""
     lib = _lib.load()
     _need_cuda(z_in, "z_in")
     _need_cuda(z_out, "z_out")
@@ -319,6 +320,5 @@ def backward_params(plan: FlowPlan, params: Sequence[torch.Tensor], z_in: torch.
                                       0 if ll_scale is None else 1, float(ll_scale or 0.0), _ptr(g_in), _ptr(ws),
                                       _stream_ptr(z_out.device))
     _lib.check(rc, "lsnf_backward_params")
-    if want_grad_z:
-        return grads, g_in
-    return grads
+    out = (grads,) + ((g_in,) if want_grad_z else ()) + ((flat,) if want_flat else ())
+    return out if len(out) > 1 else grads

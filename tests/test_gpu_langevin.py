@@ -134,6 +134,16 @@ def test_sampler_and_mle_step_harness_vs_oracle(lsnf, gpu_device):
     net.mle_grads(z2d, accumulate=True)
     for k in ref:
         assert (net.get_parameter(k).grad - 2 * ref[k]).norm().item() <= 2e-5 * max(ref[k].norm().item(), 1e-3), k
+    # clipping on the flat buffer == torch's clip_grad_norm_ (train.py:413-414)
+    total = float(torch.sqrt(sum((g ** 2).sum() for g in ref.values())))
+    net.zero_grad(set_to_none=True)
+    net.mle_grads(z2d, max_norm=0.5 * total)
+    for k in ref:
+        assert (net.get_parameter(k).grad - 0.5 * ref[k]).norm().item() <= 2e-5 * max(ref[k].norm().item(), 1e-3), k
+    net.zero_grad(set_to_none=True)
+    net.mle_grads(z2d, max_norm=10.0 * total)          # above the norm: untouched
+    for k in ref:
+        assert (net.get_parameter(k).grad - ref[k]).norm().item() <= 1e-5 * max(ref[k].norm().item(), 1e-3), k
     l2 = lsnf.langevin.flow_mle_step(net, opt, zk, f_max_norm=100.0, fused=True)
     l3 = lsnf.langevin.flow_mle_step(net, opt, zk, f_max_norm=100.0, fused=True)
     assert l3.item() < l2.item() <= l1.item()
