@@ -11,8 +11,8 @@ flow-MLE Adam step -- for the four dataset geometries of the reference's README,
 Multi-GPU: one process per GPU (RCCL); the image batch and the latents are sharded by rank, the generator is wrapped
 in stock DistributedDataParallel, the flow's parameter gradients travel as ONE flat bucket
 (`lsnf_amd.parallel.allreduce_gradients`), its weights are broadcast once.  The Langevin loop itself needs no
-communication (per-sample).  The generator is a stock DCGAN-style ConvTranspose2d stack of the dataset's output
-shape -- a stand-in: the reference's `_netG` (MIOpen convolutions) is outside the scope of the hand-written kernels.
+communication (per-sample).  The generator is `lsnf_amd._netG`, the table-driven mirror of the reference's `_netG`
+(model.py:48-157: stock ConvTranspose2d stacks, i.e. MIOpen), `--no-tune` leaves MIOpen's find mode and channels-last off.
 Prints one JSON line per run (rank 0): ms/iteration and the flow's share of it."""
 import argparse
 import json
@@ -34,15 +34,18 @@ GEOMETRY = {"svhn": (32, 100, 64, 64, 20), "cifar10": (32, 128, 128, 64, 40),
             "celeba": (64, 100, 128, 64, 20), "celeba_hq256": (256, 100, 128, 128, 20)}
 
 
-def make_generator(nz, ngf, nc, size):
-    """4x4 seed, then x2 per layer until `size`; channels halve from 8*ngf down to ngf; LeakyReLU(0.2); tanh output."""
-    layers, ch, hw = [nn.ConvTranspose2d(nz, ngf * 8, 4, 1, 0), nn.LeakyReLU(0.2)], ngf * 8, 4
-    while hw * 2 < size:
-        nxt = max(ngf, ch // 2)
-        layers += [nn.ConvTranspose2d(ch, nxt, 4, 2, 1), nn.LeakyReLU(0.2)]
-        ch, hw = nxt, hw * 2
-    layers += [nn.ConvTranspose2d(ch, nc, 4, 2, 1), nn.Tanh()]
-    return nn.Sequential(*layers)
+REF_DATASET = {"svhn": "svhn", "cifar10": "cifar10", "celeba": "celeba_crop", "celeba_hq256": "celeba_hq256"}
+
+
+def make_generator(dataset, nz, ngf, nc, tune):
+    """The reference's generator for this dataset (train.py:266-267: `_netG(args)` + xavier init)."""
+    gargs = types.SimpleNamespace(dataset=REF_DATASET[dataset], nz=nz, ngf=ngf, nc=nc, g_activation="lrelu",
+                                  g_activation_leak=0.2, g_batchnorm=False)
+    net = lsnf_amd._netG(gargs)
+    for m in net.modules():
+        if isinstance(m, nn.ConvTranspose2d):
+            nn.init.xavier_normal_(m.weight)
+    return net.tune() if tune else net
 
 
 def main():
@@ -51,6 +54,7 @@ def main():
     ap.add_argument("--batch", type=int, default=100, help="images per GPU (reference: 100, train.py:46)")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-tune", action="store_true", help="generator without channels-last / MIOpen find mode")
     args = ap.parse_args()
     size, nz, ngf, f_width, K = GEOMETRY[args.dataset]
     step_size, sigma, nc, B = 0.1, 0.3, 3, args.batch
@@ -61,7 +65,9 @@ def main():
     rank, world, _ = parallel.init_from_env(dev)
     torch.manual_seed(1); np.random.seed(1)                     # same initial weights on every rank
     hps = types.SimpleNamespace(f_n_levels=1, f_depth=5, f_flow_permutation=2, f_width=f_width, f_flow_coupling=1)
-    netG = make_generator(nz, ngf, nc, size).to(dev)
+    netG = make_generator(args.dataset, nz, ngf, nc, not args.no_tune).to(dev)
+    if not args.no_tune:
+        netG = netG.to(memory_format=torch.channels_last)
     netF = lsnf_amd._netF(hps, nz=nz).to(dev)
     parallel.broadcast_parameters(netF._param_list())
     if world > 1:
@@ -109,6 +115,9 @@ def main():
     ms_iter, (lg, lf) = wall(iteration, args.iters)
     z2d = torch.randn(B, nz, device=dev); gg = torch.randn(B, nz, device=dev); nn_ = torch.randn(B, nz, device=dev)
     ms_flow, _ = wall(lambda: netF.langevin_step(z2d, gg, nn_, step_size), 200)
+    gmod = netG.module if world > 1 else netG
+    z4 = torch.randn(B, nz, 1, 1, device=dev)
+    ms_gen, _ = wall(lambda: lsnf_amd.netg.langevin_grad_g(gmod, z4, x, sigma), 20)
     zk = torch.randn(B, nz, 1, 1, device=dev)
     ms_mle, _ = wall(lambda: langevin.flow_mle_step(netF, optF, zk, f_max_norm=100.0, fused=True), 20)
     if world > 1:
@@ -119,6 +128,8 @@ def main():
         print(json.dumps({"config": f"{args.dataset} {size}x{size} nz={nz} ngf={ngf} f_width={f_width} g_l_steps={K} "
                                     f"B={B}/GPU x {world} GPU(s), synthetic x",
                           "ms_per_iteration": ms_iter, "iterations_per_s": 1e3 / ms_iter, "images_per_s": world * B * 1e3 / ms_iter,
+                          "generator": "reference-shaped _netG" + ("" if args.no_tune else ", channels-last + MIOpen find mode"),
+                          "generator_langevin_grad_ms": ms_gen,
                           "flow_langevin_step_ms": ms_flow, "flow_mle_step_ms": ms_mle,
                           "flow_share_of_iteration": (K * ms_flow + ms_mle) / ms_iter,
                           "loss_g": lg.item(), "loss_f": lf.item()}), flush=True)

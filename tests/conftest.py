@@ -19,7 +19,7 @@ def pytest_configure(config):
 
 def golden_names():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                  if not os.path.basename(p).startswith("langevin"))
+                  if not os.path.basename(p).startswith(("langevin", "netg")))
 
 
 def load_golden(name):

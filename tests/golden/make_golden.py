@@ -179,6 +179,44 @@ def run_langevin(name, nz=100, width=64, B=16, K=3, ngf=8, seed=5):
     print(f"{name}: K={K} f_log_lkhd={f_l} -> {os.path.getsize(path) / 1e6:.2f} MB")
 
 
+def synthetic_image(B, size):
+    """RNG-free target image (the tests rebuild it from this formula instead of storing 256x256 pixels)."""
+    b, c, i, j = np.meshgrid(np.arange(B), np.arange(3), np.arange(size), np.arange(size), indexing="ij")
+    return torch.from_numpy(np.tanh(np.sin(0.37 * i + 0.91 * j + 1.7 * c + 2.3 * b)).astype(np.float32))
+
+
+def netg_cases():
+    """The reference's generator `_netG` (model.py:48-157), every dataset variant at a small ngf: weights, z, the image
+    (sub-sampled for the larger sizes) and the Langevin z-gradient of train.py:312-314."""
+    out = {}
+    for ds, size, nz, ngf, B, sub in (("svhn", 32, 12, 4, 3, 1), ("cifar10", 32, 12, 4, 3, 1),
+                                      ("celeba_crop", 64, 10, 3, 2, 2), ("celeba_hq256", 256, 8, 2, 2, 8)):
+        for act, bn in (("lrelu", False), ("swish", True)) if ds == "svhn" else (("lrelu", False),):
+            tag = f"{ds}_{act}_bn{int(bn)}"
+            torch.manual_seed(31 + len(out))
+            gargs = types.SimpleNamespace(dataset=ds, nz=nz, ngf=ngf, nc=3, g_activation=act, g_activation_leak=0.2,
+                                          g_batchnorm=bn)
+            netG = ref._netG(gargs)
+            netG.apply(ref.weights_init_xavier)
+            netG.eval()
+            g = torch.Generator().manual_seed(77)
+            z = torch.randn(B, nz, 1, 1, generator=g, requires_grad=True)
+            x = synthetic_image(B, size)
+            x_hat = netG(z)
+            gl = torch.nn.MSELoss(reduction="sum")(x_hat, x) / (2.0 * 0.3 * 0.3)
+            (zg,) = torch.autograd.grad(gl, z)
+            out[f"{tag}/meta"] = np.array([size, nz, ngf, B, sub], dtype=np.int64)
+            out[f"{tag}/z"] = z.detach().numpy().copy()
+            out[f"{tag}/x_hat"] = x_hat.detach()[:, :, ::sub, ::sub].numpy().copy()
+            out[f"{tag}/g_log_lkhd"] = np.float64(gl.item())
+            out[f"{tag}/z_grad_g"] = zg.numpy().copy()
+            for k, v in netG.state_dict().items():
+                out[f"{tag}/sd/{k}"] = v.detach().numpy().copy()
+    path = os.path.join(HERE, "netg_variants.npz")
+    np.savez(path, **out)
+    print(f"netg_variants: {sorted({k.split('/')[0] for k in out})} -> {os.path.getsize(path) / 1e6:.2f} MB")
+
+
 def affine_cases():
     # tiny (all kernels' padding paths), odd B
     run_case("tiny_nz8_w4_B7", 8, 4, 7, 1.0, seed=11)
@@ -207,3 +245,5 @@ if __name__ == "__main__":
         affine_cases()
     if "additive" in which:
         additive_cases()
+    if "netg" in which:
+        netg_cases()

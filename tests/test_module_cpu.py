@@ -118,3 +118,39 @@ def test_pick_device_without_gpu_is_loud(monkeypatch):
     assert parallel.pick_device(prefer_free=False) == torch.device("cuda", 0)
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda i: ((10, 50, 30, 20)[i], 100))
     assert parallel.pick_device() == torch.device("cuda", 1)
+
+
+def _synthetic_image(B, size):
+    b, c, i, j = np.meshgrid(np.arange(B), np.arange(3), np.arange(size), np.arange(size), indexing="ij")
+    return torch.from_numpy(np.tanh(np.sin(0.37 * i + 0.91 * j + 1.7 * c + 2.3 * b)).astype(np.float32))
+
+
+def test_generator_mirror_matches_reference_golden():
+    """`lsnf_amd.netg._netG` (stock PyTorch / MIOpen, table-driven) against the reference's `_netG`
+    (model.py:48-157) for every dataset variant: identical state_dict keys and shapes, image and Langevin z-gradient
+    (train.py:312-314) equal to fp32 rounding.  Fixture: tests/golden/netg_variants.npz (make_golden.py netg)."""
+    from lsnf_amd import netg
+    raw = np.load(os.path.join(ROOT, "tests", "golden", "netg_variants.npz"), allow_pickle=False)
+    tags = sorted({k.split("/")[0] for k in raw.files})
+    assert len(tags) == 5
+    for tag in tags:
+        ds, act, bn = tag.rsplit("_", 2)
+        size, nz, ngf, B, sub = (int(v) for v in raw[f"{tag}/meta"])
+        args = types.SimpleNamespace(dataset=ds, nz=nz, ngf=ngf, nc=3, g_activation=act, g_activation_leak=0.2,
+                                     g_batchnorm=bn == "bn1")
+        net = netg._netG(args).eval()
+        sd = {k[len(tag) + 4:]: torch.from_numpy(raw[k]) for k in raw.files if k.startswith(tag + "/sd/")}
+        assert sorted(net.state_dict()) == sorted(sd)
+        net.load_state_dict(sd, strict=True)
+        z = torch.from_numpy(raw[f"{tag}/z"])
+        x = _synthetic_image(B, size)
+        with torch.no_grad():
+            x_hat = net(z)
+        assert x_hat.shape == (B, 3, size, size)
+        assert (x_hat[:, :, ::sub, ::sub] - torch.from_numpy(raw[f"{tag}/x_hat"])).abs().max().item() <= 1e-5
+        zg, gl = netg.langevin_grad_g(net, z, x, 0.3)
+        ref = torch.from_numpy(raw[f"{tag}/z_grad_g"])
+        assert abs(gl.item() - float(raw[f"{tag}/g_log_lkhd"])) <= 1e-5 * abs(float(raw[f"{tag}/g_log_lkhd"]))
+        assert (zg - ref).norm().item() <= 1e-4 * ref.norm().item()
+    with pytest.raises(ValueError):
+        netg._netG(types.SimpleNamespace(dataset="mnist", nz=8, ngf=2, nc=1, g_activation="lrelu", g_batchnorm=False))
