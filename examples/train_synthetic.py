@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--batch", type=int, default=100, help="images per GPU (reference: 100, train.py:46)")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-graph", action="store_true", help="eager Langevin loop instead of the HIP-graph replay of one step")
     ap.add_argument("--no-tune", action="store_true", help="generator without channels-last / MIOpen find mode")
     args = ap.parse_args()
     size, nz, ngf, f_width, K = GEOMETRY[args.dataset]
@@ -82,6 +83,10 @@ def main():
     x = torch.tanh(torch.randn(B, nc, size, size, device=dev, generator=gen))
 
     it = [0]
+    sampler = None
+    if not args.no_graph:       # one Langevin step (generator gradient + fused flow update) captured once, replayed K times
+        sampler = langevin.GraphedLangevinSampler(netG.module if world > 1 else netG, netF, B, nz, x.shape,
+                                                  g_l_step_size=step_size, g_llhd_sigma=sigma, seed=1234, row0=rank * B)
 
     def iteration():
         z0 = torch.randn(B, nz, 1, 1, device=dev, generator=gen)
@@ -90,8 +95,11 @@ def main():
         # (row0 = rank*B) and the global step count, so the draws do not depend on how the rows are sharded
         noise = lsnf_amd.flow.PhiloxNoise(seed=1234, offset=it[0] * K, row0=rank * B)
         it[0] += 1
-        zk, ggn, gfn, f = langevin.sample_langevin_post_z_with_flow(z0, x, gmod, netF, g_l_steps=K, g_l_step_size=step_size,
-                                                                    g_llhd_sigma=sigma, g_l_with_noise=True, philox=noise)
+        if sampler is not None:
+            zk, ggn, gfn, f = sampler.run(z0, x, K, offset=noise.offset)
+        else:
+            zk, ggn, gfn, f = langevin.sample_langevin_post_z_with_flow(z0, x, gmod, netF, g_l_steps=K, g_l_step_size=step_size,
+                                                                        g_llhd_sigma=sigma, g_l_with_noise=True, philox=noise)
         optG.zero_grad()
         loss_g = mse(netG(zk), x) / B                           # train.py:391-393 (DDP averages the gradients)
         loss_g.backward()
@@ -129,6 +137,7 @@ def main():
                                     f"B={B}/GPU x {world} GPU(s), synthetic x",
                           "ms_per_iteration": ms_iter, "iterations_per_s": 1e3 / ms_iter, "images_per_s": world * B * 1e3 / ms_iter,
                           "generator": "reference-shaped _netG" + ("" if args.no_tune else ", channels-last + MIOpen find mode"),
+                          "langevin_loop": "eager" if args.no_graph else "one step captured in a HIP graph, replayed K times",
                           "generator_langevin_grad_ms": ms_gen,
                           "flow_langevin_step_ms": ms_flow, "flow_mle_step_ms": ms_mle,
                           "flow_share_of_iteration": (K * ms_flow + ms_mle) / ms_iter,

@@ -65,3 +65,59 @@ def flow_mle_step(netF, optF, z_g_k, f_max_norm: Optional[float] = None, fused: 
         torch.nn.utils.clip_grad_norm_(netF.parameters(), f_max_norm)                        # train.py:413-414
     optF.step()
     return loss_f.detach()
+
+
+class GraphedLangevinSampler:
+    """The K-step sampler above with ONE step captured in a HIP graph and replayed K times (train.py:311-329).
+
+    At the reference's batch size (B = 100) a Langevin step is ~20 small launches (generator forward + input
+    gradient through MIOpen, the flow's two kernels) and the host cannot issue them as fast as the GPU retires
+    them; a graph replay issues the whole step with one call.  The step works on static buffers (z is updated in
+    place by the fused flow update), the Langevin noise is drawn inside the update kernel from a device-side
+    counter that the graph itself advances (`PhiloxNoise(offset_dev=)`), and the flow's prepared weights live in a
+    buffer that `netF._plan()` refreshes in place -- so optimizer steps between `run()` calls need no re-capture.
+
+        sampler = GraphedLangevinSampler(netG, netF, B, nz, x_shape, g_l_step_size=0.1, g_llhd_sigma=0.3, seed=1)
+        z_k, gg_norm, gf_norm, f = sampler.run(z0, x, g_l_steps=20, offset=it * 20)
+    """
+
+    def __init__(self, netG: nn.Module, netF, B: int, nz: int, x_shape, *, g_l_step_size: float, g_llhd_sigma: float,
+                 g_l_with_noise: bool = True, seed: int = 0, row0: int = 0, device=None, warmup: int = 3):
+        from . import flow
+        dev = device or next(netF.parameters()).device
+        self.netG, self.netF, self.B, self.nz = netG, netF, B, nz
+        self.z = torch.zeros(B, nz, 1, 1, device=dev)
+        self.x = torch.zeros(tuple(x_shape), device=dev)
+        self.ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.noise = flow.PhiloxNoise(seed, 0, row0, offset_dev=self.ctr) if g_l_with_noise else None
+        self.s, self.sigma = float(g_l_step_size), float(g_llhd_sigma)
+        self.mse = nn.MSELoss(reduction="sum")
+        netF._plan()                                   # prepared weights exist before anything is captured
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                  # warm-up off the capture stream (MIOpen finds its solvers here)
+            for _ in range(warmup):
+                self._step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.f_log_lkhd, self.gg_norm, self.gf_norm = self._step()
+
+    def _step(self):
+        zr = self.z.detach().requires_grad_(True)
+        g_log_lkhd = 1.0 / (2.0 * self.sigma * self.sigma) * self.mse(self.netG(zr), self.x)         # train.py:312-313
+        z_grad_g = torch.autograd.grad(g_log_lkhd, zr)[0]                                            # train.py:314
+        _, ll, gf, gg = self.netF.langevin_step(self.z.view(self.B, self.nz), z_grad_g.reshape(self.B, self.nz),
+                                                self.noise, self.s, inplace=True)                    # :316-326, in place
+        self.ctr.add_(1)                                                                             # next step's noise
+        return -ll.sum(), gg.mean(), gf.mean()
+
+    def run(self, z0: torch.Tensor, x: torch.Tensor, g_l_steps: int, offset: int = 0):
+        """Returns (z_k (B,nz,1,1), mean |z_grad_g|, mean |z_grad_f|, f_log_lkhd of the last step's input)."""
+        self.z.copy_(z0.reshape(self.z.shape))
+        self.x.copy_(x)
+        self.ctr.fill_(int(offset))
+        self.netF._plan()                              # re-derives the prepared weights in place if a parameter changed
+        for _ in range(g_l_steps):
+            self.graph.replay()
+        return self.z.detach().clone(), self.gg_norm, self.gf_norm, self.f_log_lkhd

@@ -197,3 +197,30 @@ def test_in_kernel_philox_noise_full_size_moments(lsnf, gpu_device):
     assert abs((n[:, 1:] * n[:, :-1]).mean().item()) < 2e-3 and abs((n[1:] * n[:-1]).mean().item()) < 2e-3
     n2 = ((lsnf.langevin_step(plan, z, None, lsnf.flow.PhiloxNoise(99, 2), 0.25)[0] - base) / 0.25).double()
     assert abs((n * n2).mean().item()) < 2e-3
+
+
+def test_graphed_sampler_matches_eager(lsnf, gpu_device):
+    """One Langevin step captured in a HIP graph and replayed K times == the eager sampler, with the in-kernel noise
+    advanced by the graph's own device counter; an optimizer step between two runs needs no re-capture."""
+    nz, width, B, K, s, sigma = 20, 12, 37, 4, 0.1, 0.3
+    p = O.init_params(nz, width, 5, seed=31)
+    net = make_net(lsnf, p, nz, width, 5, gpu_device)
+    torch.manual_seed(5)
+    gargs = types.SimpleNamespace(dataset="svhn", nz=nz, ngf=4, nc=3, g_activation="lrelu", g_activation_leak=0.2,
+                                  g_batchnorm=False)
+    netG = lsnf._netG(gargs).to(gpu_device)
+    gen = torch.Generator().manual_seed(6)
+    z0 = torch.randn(B, nz, 1, 1, generator=gen).to(gpu_device)
+    x = torch.tanh(torch.randn(B, 3, 32, 32, generator=gen)).to(gpu_device)
+    sampler = lsnf.langevin.GraphedLangevinSampler(netG, net, B, nz, x.shape, g_l_step_size=s, g_llhd_sigma=sigma, seed=9)
+    for trial in range(2):
+        zg, ggn, gfn, f = sampler.run(z0, x, K, offset=100 * trial)
+        ze, ggn_e, gfn_e, f_e = lsnf.langevin.sample_langevin_post_z_with_flow(
+            z0, x, netG, net, g_l_steps=K, g_l_step_size=s, g_llhd_sigma=sigma,
+            philox=lsnf.flow.PhiloxNoise(9, 100 * trial))
+        assert (zg - ze).abs().max().item() <= 1e-5
+        assert abs(f.item() - f_e.item()) <= 1e-5 * abs(f_e.item())
+        assert abs(ggn.item() - ggn_e.item()) <= 1e-5 * ggn_e.item() and abs(gfn.item() - gfn_e.item()) <= 1e-5 * gfn_e.item()
+        with torch.no_grad():                      # "optimizer step": both networks change in place
+            for q in list(net.parameters()) + list(netG.parameters()):
+                q.add_(0.01 * torch.randn_like(q))
