@@ -1,0 +1,30 @@
+"""Copies what tools/round_measure.sh left under gpurun_out/round/ into profiles/ under a tag (default r01_e) and
+re-derives the summaries (traffic.json for the default arithmetic mode, kernel-only averages from the trace)."""
+import csv, glob, json, os, shutil, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01_e"
+R, P = os.path.join(ROOT, "gpurun_out", "round"), os.path.join(ROOT, "profiles")
+last = lambda f: open(f).read().strip().splitlines()[-1] + "\n"
+open(os.path.join(P, f"{tag}_bench.json"), "w").write(last(os.path.join(R, "bench.json")))
+open(os.path.join(P, f"{tag}_bench_fp32.json"), "w").write(last(os.path.join(R, "bench_fp32.json")))
+shutil.copy(os.path.join(R, "prof", "bench_kernel_stats.csv"), os.path.join(P, f"{tag}_bench_kernel_stats.csv"))
+os.makedirs(os.path.join(P, f"{tag}_pmc"), exist_ok=True)
+for p in ("p1", "p2", "p3", "p4"):
+    shutil.copy(glob.glob(os.path.join(R, "pmc", p, "*", "*_counter_collection.csv"))[0], os.path.join(P, f"{tag}_pmc", f"{p}_counter_collection.csv"))
+shutil.copy(os.path.join(R, "secondary.json"), os.path.join(P, f"{tag}_secondary.json"))
+shutil.copy(os.path.join(R, "train_configs.jsonl"), os.path.join(P, f"{tag}_train_configs.jsonl"))
+rows = list(csv.DictReader(open(os.path.join(R, "prof", "bench_kernel_trace.csv"))))
+out = {}
+for key, name in (("fwd3", "lsnf_fwd3_kernel<Fwd3Cfg<2,2>>"), ("lsnf_fwd_kernel", "lsnf_fwd_kernel<FwdCfg<2,2>, 8>")):
+    rr = sorted((r for r in rows if key in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rr]
+    out[name] = {"dispatches_in_trace": len(d), "kernel_only_loop_last_200_avg_us": sum(d[-200:]) / 200, "min_us": min(d[-200:]), "max_us": max(d[-200:])}
+out["note"] = ("per-dispatch durations from rocprofv3 --kernel-trace of `python3 bench.py --steps 300 --warmup 100 --no-cpu-baseline`; "
+               "the timed steps alternate over 2 HIP streams, so their kernels overlap and the all-dispatch average of the "
+               "kernel_stats csv is NOT a kernel duration; bench.py's roofline uses its single-stream kernel-only loop "
+               "(the last 200 dispatches of each kernel), which is what is averaged here")
+json.dump(out, open(os.path.join(P, f"{tag}_kernel_only_from_trace.json"), "w"), indent=1)
+subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_traffic.py"), os.path.join(R, "pmc"), "bf16x3"], cwd=ROOT, check=True)
+b = json.loads(last(os.path.join(R, "bench.json")))
+print(tag, "value %.4g" % b["value"], "ms/step %.4f" % b["ms_per_step"], "kernel_ms %.4f" % b["roofline"]["kernel_ms"], "frac %.3f" % b["roofline"]["frac"],
+      "| fp32 kernel_ms %.4f" % b["config"]["other_math_mode"]["kernel_ms"], "| trace", {k: round(v["kernel_only_loop_last_200_avg_us"], 1) for k, v in out.items() if k != "note"})
