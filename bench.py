@@ -226,7 +226,10 @@ def main():
             rl = {"bound": "mfma", "achieved": SPLIT_MFMA_PER_PRODUCT * tflops, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                   "frac": SPLIT_MFMA_PER_PRODUCT * tflops / PEAK_BF16_MFMA_TFLOPS, "kernel": "lsnf_fwd3_kernel<Fwd3Cfg<2,2>>",
                   "note": "executed bf16 MFMA flops (6 per algorithmic flop) vs the dense bf16 peak; algorithmic_tflops is "
-                          "the fp32-equivalent rate, 1.0 of the fp32 MFMA peak would be 157.3"}
+                          "the fp32-equivalent rate, 1.0 of the fp32 MFMA peak would be 157.3.  Calibration (tools/micro/"
+                          "mfma_bf16_shapes.hip, DESIGN.md section 5): a bare loop of this MFMA shape sustains 1628 TFLOP/s on "
+                          "random operands (the chip holds 1.93 GHz under the bf16 pipe), 2274 on zeros",
+                  "bare_mfma_loop_on_random_operands_tflops": 1628.0}
         else:
             rl = {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                   "frac": tflops / PEAK_FP32_MFMA_TFLOPS, "kernel": "lsnf_fwd_kernel<FwdCfg<2,2>, 8>"}
