@@ -61,7 +61,9 @@ const char* lsnf_last_error(void);
 
 /* Tuning knob: batches of at most `rows` rows run on the small-batch (latency) kernels, larger ones on the
  * throughput kernels; both compute the same function (results agree to fp32 rounding, not bit for bit).
- * rows < 0 only queries.  Returns the previous value (default 16384, or the LSNF_SMALL_MAX environment variable). */
+ * rows < 0 only queries.  Returns the previous value (default 16384, or the LSNF_SMALL_MAX environment variable).
+ * In the LSNF_MATH_BF16X3 mode the FORWARD switches at min(rows, 8192): its throughput kernel overtakes the latency
+ * kernel earlier. */
 int lsnf_set_small_batch_max(int rows);
 
 /* Arithmetic of the GEMMs in the throughput forward kernel (batches above the small-batch threshold):

@@ -14,8 +14,8 @@
 // the weights are split once in lsnf_prepare (plan region off_f3_panels, 6 KiB per 32x32 block instead of 4),
 // the activations on the fly (4.5 VALU per element: v_cvt_pk_bf16_f32, shift/and, v_pk_add_f32).
 //
-// Work decomposition: one workgroup of 8 waves per CU (the two 48 KiB weight buffers do not fit twice), wave = 32
-// samples; weights stream L2 -> LDS by LDS-DMA in panel pairs exactly as in lsnf_fwd.hip.  Because the k-slot j of
+// Work decomposition: one workgroup per CU (the two 48 KiB weight buffers do not fit twice) of 8 waves (batches above
+// 32 768 rows) or 4 waves, wave = 32 samples; weights stream L2 -> LDS by LDS-DMA in panel pairs exactly as in lsnf_fwd.hip.  Because the k-slot j of
 // lane-half h in k-step s is accumulator register 8*s + j (lsnf_layout.h), an output tile converted to bf16 pairs in
 // register order is directly the next GEMM's B operand.
 #include "lsnf_device.h"
@@ -27,7 +27,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int F3_WAVES = 8;
 
 template <int HT_, int WT_>
 struct Fwd3Cfg : LsnfStackCfg<HT_, WT_> {
@@ -96,24 +95,25 @@ __device__ __forceinline__ void split_tiles(const f32x16* x, Split3* out) {   //
 }
 
 // LDS-DMA of KB KiB (1 KiB per wave-instruction), as lsnf_issue_panel
-template <int KB>
+template <int KB, int NW>
 __device__ __forceinline__ void issue_kib(const float* __restrict__ gsrc, float* lbuf, int wave, int lane) {
-    constexpr int PER_WAVE = (KB + F3_WAVES - 1) / F3_WAVES;
+    constexpr int PER_WAVE = (KB + NW - 1) / NW;
 #pragma unroll
     for (int s = 0; s < PER_WAVE; ++s) {
-        const int seg = s * F3_WAVES + wave;
-        if (KB % F3_WAVES == 0 || seg < KB) {      // wave-uniform
+        const int seg = s * NW + wave;
+        if (KB % NW == 0 || seg < KB) {      // wave-uniform
             __builtin_amdgcn_global_load_lds((const LSNF_AS1 void*)(gsrc + seg * 256 + lane * 4),
                                              (LSNF_AS3 void*)(lbuf + seg * 256), 16, 0, 0);
         }
     }
 }
+template <int NW>
 struct Pipe3 {
     float* buf0; int slot, cur, wave, lane;
-    template <int KB> __device__ __forceinline__ void prime(const float* src) { issue_kib<KB>(src, buf0, wave, lane); cur = 0; }
+    template <int KB> __device__ __forceinline__ void prime(const float* src) { issue_kib<KB, NW>(src, buf0, wave, lane); cur = 0; }
     template <int KB_NEXT> __device__ __forceinline__ const float* acquire(const float* next) {
         lsnf_panel_barrier();
-        if (next != nullptr) issue_kib<KB_NEXT>(next, buf0 + (cur ^ 1) * slot, wave, lane);
+        if (next != nullptr) issue_kib<KB_NEXT, NW>(next, buf0 + (cur ^ 1) * slot, wave, lane);
         const float* ready = buf0 + cur * slot;
         cur ^= 1;
         return ready;
@@ -170,8 +170,8 @@ __device__ __forceinline__ void panel_mma3(f32x16& acc0, f32x16& acc1, const Spl
 }
 
 // one GEMM stage out[t] = post(init(t) + W_t^T in), streamed as panel pairs (cf. lsnf_gemm_stage)
-template <int NT, int KT, int NEXT_KIB, class Init, class Post>
-__device__ __forceinline__ void gemm_stage3(Pipe3& pipe, const float* gsrc, const float* gnext, f32x16* out, const Split3* in,
+template <int NT, int KT, int NEXT_KIB, class Pipe, class Init, class Post>
+__device__ __forceinline__ void gemm_stage3(Pipe& pipe, const float* gsrc, const float* gnext, f32x16* out, const Split3* in,
                                             Init&& init, Post&& post) {
     constexpr int NSP = (NT + 1) / 2;
     lsnf_static_for<NSP>([&](auto qc) {
@@ -195,7 +195,9 @@ __device__ __forceinline__ void gemm_stage3(Pipe3& pipe, const float* gsrc, cons
     });
 }
 
-template <class C>
+// F3_WAVES waves per workgroup, one workgroup per CU either way (the weight buffers): 8 = two waves per SIMD, 256 rows;
+// 4 = one wave per SIMD, 128 rows -- twice the workgroups for batches that would leave CUs idle with 256-row groups
+template <class C, int F3_WAVES>
 __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3_kernel(const Fwd3Args a) {
     constexpr int THREADS = 64 * F3_WAVES;
     constexpr int HT = C::HT, WT = C::WT, NZT = C::NZT;
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3_kernel(const Fwd3A
 
     F3_STAMP(0, "s_memtime");
     F3_STAMP(50, "s_memrealtime");
-    Pipe3 pipe;
+    Pipe3<F3_WAVES> pipe;
     pipe.buf0 = buf0; pipe.slot = C::SLOT3; pipe.wave = wave; pipe.lane = lane;
     pipe.template prime<first_kib(C::P1, C::KT1)>(a.panels3);
     for (int i = tid; i < a.n_blocks * C::CONST_FLOATS; i += THREADS) cst[i] = a.consts[i];
@@ -356,16 +358,21 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3_kernel(const Fwd3A
     F3_STAMP(51, "s_memrealtime");
 }
 
-template <class C>
-hipError_t launch_fwd3(const Fwd3Args& a, hipStream_t stream) {
+template <class C, int F3_WAVES>
+hipError_t launch_fwd3_w(const Fwd3Args& a, hipStream_t stream) {
     const size_t lds = ((size_t)a.n_blocks * C::CONST_FLOATS + 2 * (size_t)C::SLOT3) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = lsnf_fwd3_kernel<C>;
+    auto kern = lsnf_fwd3_kernel<C, F3_WAVES>;
     static unsigned long long lds_ok = 0;
     if (hipError_t e = lsnf_allow_big_lds((const void*)kern, &lds_ok); e != hipSuccess) return e;
     const unsigned grid = (unsigned)((a.B + 32 * F3_WAVES - 1) / (32 * F3_WAVES));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * F3_WAVES), lds, stream, a);
     return hipGetLastError();
+}
+template <class C>
+hipError_t launch_fwd3(const Fwd3Args& a, hipStream_t stream) {
+    // 256-row workgroups need B > 32768 to put one on (almost) every CU; below that 128-row workgroups use twice the CUs
+    return a.B > 128 * 256 ? launch_fwd3_w<C, 8>(a, stream) : launch_fwd3_w<C, 4>(a, stream);
 }
 }  // namespace
 

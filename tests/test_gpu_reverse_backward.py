@@ -155,3 +155,24 @@ def test_full_size_backward_properties(lsnf, gpu_device):
     z1c, _, _, savedc, actc = _fwd(lsnf, plan, zd[:B2].contiguous(), True)
     gc = lsnf.backward_z(plan, z1c, savedc, ll_scale=-1.0, act_saved=actc)
     same_up_to_kinks(gc, g[:B2])
+
+
+def test_throughput_forward_feeds_latency_backward(lsnf, gpu_device):
+    """Default dispatch at 10 000 rows: the bf16x3 throughput forward (above its 8 192-row crossover) writes z_saved and
+    the activation stash, the latency backward (below the 16 384-row threshold) reads them -- the two layouts are
+    family-independent."""
+    nz, width, depth, B = 100, 64, 5, 10000
+    p = O.init_params(nz, width, depth, seed=5)
+    plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
+    assert lsnf.flow.set_math_mode(-1) == lsnf.flow.MATH_BF16X3 and lsnf.flow.set_small_batch_max(-1) == 16384
+    z = torch.randn(B, nz, generator=torch.Generator().manual_seed(8))
+    z1, ld, ll, saved, act = _fwd(lsnf, plan, z.to(gpu_device), True)
+    g_stash = lsnf.backward_z(plan, z1, saved, ll_scale=-1.0, act_saved=act)
+    g_rec = lsnf.backward_z(plan, z1, saved, ll_scale=-1.0)
+    idx = torch.arange(3, B, 101)
+    ref = O.grad_neg_sum_ll_wrt_z(p, z[idx])
+    ok = O.relu_margin(p, z[idx]) > KINK
+    for g in (g_stash, g_rec):
+        assert ((g.cpu()[idx] - ref)[ok].norm() / ref[ok].norm()).item() <= 1e-5
+    _, _, llr = O.flow_log_prob(p, z[idx])
+    assert ((ll.cpu()[idx] - llr).abs() / llr.abs()).max().item() <= 1e-5

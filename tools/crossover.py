@@ -14,15 +14,16 @@ def timeit(fn, n):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
-for B in (32, 100, 256, 1024, 4096, 8192, 16384, 32768, 65536):
+for B in (32, 100, 256, 1024, 4096, 8192, 12288, 16384, 20480, 24576, 32768, 49152, 65536):
     z = torch.randn(B, 128, device=dev)
     res = []
-    for name, thr in (("latency", 1 << 30), ("throughput", 0)):
+    for name, thr, math in (("latency", 1 << 30, 0), ("throughput", 0, 1), ("throughput fp32", 0, 0)):
         lsnf_amd.flow.set_small_batch_max(thr)
+        lsnf_amd.flow.set_math_mode(math)
         if which == "fwd":
-            t = timeit(lambda: lsnf_amd.forward(plan, z), 100)
+            t = timeit(lambda: lsnf_amd.forward(plan, z), 300)
         else:
             z1, ld, ll, sv = lsnf_amd.forward(plan, z, save_for_backward=True)
             t = timeit(lambda: lsnf_amd.backward_z(plan, z1, sv, ll_scale=-1.0), 100)
         res.append(t)
-    print(f"{which} B={B:6d}  latency-kernel {res[0]:8.1f} us   throughput-kernel {res[1]:8.1f} us")
+    print(f"{which} B={B:6d}  latency-kernel {res[0]:8.1f} us   throughput-kernel bf16x3 {res[1]:8.1f} us   fp32 MFMA {res[2]:8.1f} us")
