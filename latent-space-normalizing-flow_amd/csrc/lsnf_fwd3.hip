@@ -98,11 +98,15 @@ __device__ __forceinline__ void split_tiles(const f32x16* x, Split3* out) {   //
 template <int KB, int NW>
 __device__ __forceinline__ void issue_kib(const float* __restrict__ gsrc, float* lbuf, int wave, int lane) {
     constexpr int PER_WAVE = (KB + NW - 1) / NW;
+    // wave-uniform base + 32-bit per-lane byte offset: the address arithmetic stays on the scalar unit / in the
+    // instruction's offset field instead of two 64-bit VALU adds per piece (VALU time is not hidden under MFMA here)
+    const char* base = reinterpret_cast<const char*>(gsrc);
+    const unsigned lane_off = (unsigned)lane * 16u;
 #pragma unroll
     for (int s = 0; s < PER_WAVE; ++s) {
         const int seg = s * NW + wave;
         if (KB % NW == 0 || seg < KB) {      // wave-uniform
-            __builtin_amdgcn_global_load_lds((const LSNF_AS1 void*)(gsrc + seg * 256 + lane * 4),
+            __builtin_amdgcn_global_load_lds((const LSNF_AS1 void*)(base + (size_t)seg * 1024u + lane_off),
                                              (LSNF_AS3 void*)(lbuf + seg * 256), 16, 0, 0);
         }
     }
