@@ -69,12 +69,16 @@ int lsnf_set_small_batch_max(int rows);
 /* Arithmetic of the GEMMs in the throughput forward kernel (batches above the small-batch threshold):
  *   LSNF_MATH_FP32   : fp32 MFMA (v_mfma_f32_32x32x2_f32)
  *   LSNF_MATH_BF16X3 : both operands split error-free into three bf16 terms, six bf16 MFMAs per product with fp32
- *                      accumulation (csrc/lsnf_fwd3.hip).  Same accuracy class as fp32 MFMA (dropped terms are
- *                      <= 2^-26 |w||x|); results agree with LSNF_MATH_FP32 to fp32 rounding, not bit for bit.
+ *                      accumulation (csrc/lsnf_fwd3.hip, on v_mfma_f32_16x16x32_bf16).  Same accuracy class as fp32
+ *                      MFMA (dropped terms are <= 2^-26 |w||x|); results agree with LSNF_MATH_FP32 to fp32 rounding,
+ *                      not bit for bit.
+ *   LSNF_MATH_BF16X3_32 : the same scheme on v_mfma_f32_32x32x16_bf16 (kept for comparison: that shape sustains a lower
+ *                      clock on real data, ~8 % slower).
  * mode < 0 only queries.  Returns the previous mode (default LSNF_MATH_DEFAULT, or the LSNF_MATH environment
- * variable "fp32" / "bf16x3"). */
+ * variable "fp32" / "bf16x3" / "bf16x3_32"). */
 #define LSNF_MATH_FP32 0
 #define LSNF_MATH_BF16X3 1
+#define LSNF_MATH_BF16X3_32 2
 #define LSNF_MATH_DEFAULT LSNF_MATH_BF16X3
 int lsnf_set_math_mode(int mode);
 

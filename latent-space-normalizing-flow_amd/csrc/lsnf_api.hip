@@ -24,7 +24,7 @@ hipError_t lsnf_launch_forward(const LsnfGeo& g, const float* plan, int first_bl
 hipError_t lsnf_launch_forward3(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                 const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                 float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
-                                hipStream_t stream);
+                                int shape16, hipStream_t stream);
 hipError_t lsnf_launch_small_forward(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                      const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                      float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
@@ -85,7 +85,8 @@ int g_math = -1;
 int math_mode() {
     if (g_math < 0) {
         const char* e = getenv("LSNF_MATH");
-        g_math = (e && !strcmp(e, "bf16x3")) ? LSNF_MATH_BF16X3 : (e && !strcmp(e, "fp32")) ? LSNF_MATH_FP32 : LSNF_MATH_DEFAULT;
+        g_math = (e && !strcmp(e, "bf16x3")) ? LSNF_MATH_BF16X3 : (e && !strcmp(e, "bf16x3_32")) ? LSNF_MATH_BF16X3_32
+               : (e && !strcmp(e, "fp32")) ? LSNF_MATH_FP32 : LSNF_MATH_DEFAULT;
     }
     return g_math;
 }
@@ -110,7 +111,7 @@ int lsnf_set_small_batch_max(int rows) {
 }
 int lsnf_set_math_mode(int mode) {
     const int prev = math_mode();
-    if (mode == LSNF_MATH_FP32 || mode == LSNF_MATH_BF16X3) g_math = mode;
+    if (mode == LSNF_MATH_FP32 || mode == LSNF_MATH_BF16X3 || mode == LSNF_MATH_BF16X3_32) g_math = mode;
     return prev;
 }
 const char* lsnf_last_error(void) { return g_err; }
@@ -181,16 +182,17 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
     // 66 vs 56 us) than the fp32 throughput kernels do (~20 K rows), so in that mode the forward switches at
     // min(small_batch_max, LSNF_F3_CROSSOVER); the backward / reverse keep small_batch_max (the activation stash and
     // z_saved are family-independent, so a throughput forward may feed a latency backward)
-    const int fwd_small_max = (math_mode() == LSNF_MATH_BF16X3 && small_batch_max() > LSNF_F3_CROSSOVER) ? LSNF_F3_CROSSOVER
+    const bool split = math_mode() == LSNF_MATH_BF16X3 || math_mode() == LSNF_MATH_BF16X3_32;
+    const int fwd_small_max = (split && small_batch_max() > LSNF_F3_CROSSOVER) ? LSNF_F3_CROSSOVER
                                                                                                          : small_batch_max();
     if (B <= fwd_small_max) {
         e = lsnf_launch_small_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
                                       z_saved, act_saved, stats, vec4, (hipStream_t)stream);
     } else {
         e = hipErrorInvalidValue;
-        if (math_mode() == LSNF_MATH_BF16X3)      // error-free split on the bf16 matrix pipe (lsnf_fwd3.hip)
+        if (split)                                // error-free split on the bf16 matrix pipe (lsnf_fwd3.hip)
             e = lsnf_launch_forward3(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
-                                     z_saved, act_saved, stats, vec4, (hipStream_t)stream);
+                                     z_saved, act_saved, stats, vec4, math_mode() == LSNF_MATH_BF16X3, (hipStream_t)stream);
         if (e == hipErrorInvalidValue)            // fp32 MFMA kernel (also: stacks too deep for fwd3's LDS budget)
             e = lsnf_launch_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
                                     z_saved, act_saved, stats, vec4, (hipStream_t)stream);

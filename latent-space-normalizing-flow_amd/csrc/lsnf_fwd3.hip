@@ -47,6 +47,7 @@ struct Fwd3Args {
     int B, nz, half, n_blocks, vec4;
     double* stats;
     unsigned long long* stamps;        // LSNF_STAMPS diagnostic build only: [waves & 2047][64] clock stamps
+    int shape16;                       // 1: the v_mfma_f32_16x16x32_bf16 variant (panels3 then points at its operand order)
 };
 
 #ifdef LSNF_STAMPS   // in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz (tools/stamps_fwd3.py)
@@ -362,13 +363,359 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3_kernel(const Fwd3A
     F3_STAMP(51, "s_memrealtime");
 }
 
+// =====================================================================================================================
+// The same kernel on v_mfma_f32_16x16x32_bf16 ("L16" lane layout of lsnf_layout.h: a wave's 32 samples are two sample
+// tiles st of 16; lane = (n = lane & 15, g = lane >> 4); register (2*ft + st)*4 + r of a 32-feature activation tile
+// holds feature 16*ft + 4*g + r of sample 16*st + n).  Same flops, same LDS traffic, same register count -- but on real
+// data the chip sustains a higher clock under this MFMA shape (tools/micro/mfma_bf16_shapes.hip: +12 %).
+// =====================================================================================================================
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// feature offset (within a 32-feature tile) of the first of the 4 registers (ft, *) of lane group g
+__device__ __forceinline__ constexpr int l16_feat0(int ft, int g) { return 16 * ft + 4 * g; }
+
+template <int HT>
+__device__ __forceinline__ f32x16 l16_load_tile(int t, const float* __restrict__ z, const long* rows, int nz, int half, int g, int vw) {
+    f32x16 x;
+    const int hh = t / HT, tt = t % HT;
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int f0 = 32 * tt + l16_feat0(ft, g), col0 = hh * half + f0, b = (2 * ft + st) * 4;
+            const float* zr = z + rows[st] * (long)nz;
+            if (vw == 4) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (f0 < half) v = *reinterpret_cast<const f32x4*>(zr + col0);
+                x[b] = v[0]; x[b + 1] = v[1]; x[b + 2] = v[2]; x[b + 3] = v[3];
+            } else if (vw == 2) {
+                f32x2 v0 = {0.f, 0.f}, v1 = {0.f, 0.f};
+                if (f0 < half) v0 = *reinterpret_cast<const f32x2*>(zr + col0);
+                if (f0 + 2 < half) v1 = *reinterpret_cast<const f32x2*>(zr + col0 + 2);
+                x[b] = v0[0]; x[b + 1] = v0[1]; x[b + 2] = v1[0]; x[b + 3] = v1[1];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[b + j] = (f0 + j < half) ? zr[col0 + j] : 0.0f;
+            }
+        }
+    return x;
+}
+template <int HT>
+__device__ __forceinline__ void l16_store_tile(int t, const f32x16& x, float* __restrict__ z, const long* rows, const bool* live,
+                                               int nz, int half, int g, int vw) {
+    const int hh = t / HT, tt = t % HT;
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            if (!live[st]) continue;
+            const int f0 = 32 * tt + l16_feat0(ft, g), col0 = hh * half + f0, b = (2 * ft + st) * 4;
+            float* zr = z + rows[st] * (long)nz;
+            if (vw == 4) {
+                if (f0 < half) { f32x4 v = {x[b], x[b + 1], x[b + 2], x[b + 3]}; *reinterpret_cast<f32x4*>(zr + col0) = v; }
+            } else if (vw == 2) {
+                if (f0 < half) { f32x2 v = {x[b], x[b + 1]}; *reinterpret_cast<f32x2*>(zr + col0) = v; }
+                if (f0 + 2 < half) { f32x2 v = {x[b + 2], x[b + 3]}; *reinterpret_cast<f32x2*>(zr + col0 + 2) = v; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (f0 + j < half) zr[col0 + j] = x[b + j];
+            }
+        }
+}
+// bias block of one n-tile ([h][r] order of the 32x32 layout, lsnf_prep.hip bias_feature) -> L16 accumulators
+__device__ __forceinline__ f32x16 l16_bias_init(const float* cst, int g) {
+    f32x16 a;
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(cst + (g & 1) * 16 + 4 * (2 * ft + (g >> 1)));
+#pragma unroll
+        for (int st = 0; st < 2; ++st) { const int b = (2 * ft + st) * 4; a[b] = v[0]; a[b + 1] = v[1]; a[b + 2] = v[2]; a[b + 3] = v[3]; }
+    }
+    return a;
+}
+// one activation tile -> the three bf16 terms of its two sample tiles (B operands of K = 32: slots 0..3 from ft = 0, 4..7 from ft = 1)
+__device__ __forceinline__ void l16_split_tile(const f32x16& x, Split3& s0, Split3& s1) {
+    u32x4 w[2][3];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {          // pair q: ft = q >> 1, registers 2*(q&1), 2*(q&1)+1
+            const int b = (2 * (q >> 1) + st) * 4 + 2 * (q & 1);
+            float a = x[b], c = x[b + 1];
+            const unsigned p1 = pk_bf16(a, c);
+            a -= __builtin_bit_cast(float, p1 << 16); c -= __builtin_bit_cast(float, p1 & 0xffff0000u);
+            const unsigned p2 = pk_bf16(a, c);
+            a -= __builtin_bit_cast(float, p2 << 16); c -= __builtin_bit_cast(float, p2 & 0xffff0000u);
+            w[st][0][q] = p1; w[st][1][q] = p2; w[st][2][q] = pk_bf16(a, c);
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { s0.p[i] = __builtin_bit_cast(bf16x8, w[0][i]); s1.p[i] = __builtin_bit_cast(bf16x8, w[1][i]); }
+}
+template <int KT>
+__device__ __forceinline__ void l16_split_tiles(const f32x16* x, Split3* out) {   // out[2*KT]: [kt][st]
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) l16_split_tile(x[kt], out[2 * kt], out[2 * kt + 1]);
+}
+
+// NTILES n-tiles x KT k-tiles out of one LDS buffer.  A step = (n-tile, k-tile, ft): 3 fragment reads (the three weight
+// parts of 16 output features) feed 12 MFMAs (6 terms x 2 sample tiles); the next step's reads are issued first.
+template <int KT, int NTILES>
+__device__ __forceinline__ void l16_panel_mma3(f32x16& acc0, f32x16& acc1, const Split3* in, const float* lbuf, int lane) {
+    const bf16x8* wp = reinterpret_cast<const bf16x8*>(lbuf) + lane;
+    constexpr int STEPS = 2 * KT * NTILES;
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 a[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) a[p] = wp[p * 64];
+    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+    f32x4v c[2][2][2];                                   // [tile][ft][st]
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { c[0][ft][st][r] = acc0[(2 * ft + st) * 4 + r]; c[1][ft][st][r] = acc1[(2 * ft + st) * 4 + r]; }
+#pragma unroll
+    for (int idx = 0; idx < STEPS; ++idx) {
+        const int tile = idx / (2 * KT), kt = (idx % (2 * KT)) / 2, ft = idx & 1;
+        bf16x8 na[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) na[p] = a[p];
+        if (idx + 1 < STEPS) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) na[p] = wp[((idx + 1) * 3 + p) * 64];
+        }
+#define LSNF_F3_MMA(WI, XI)                                                                                                        \
+        c[tile][ft][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[WI], in[2 * kt + 0].p[XI], c[tile][ft][0], 0, 0, 0);         \
+        c[tile][ft][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[WI], in[2 * kt + 1].p[XI], c[tile][ft][1], 0, 0, 0);
+        LSNF_F3_TERMS(LSNF_F3_MMA)
+#undef LSNF_F3_MMA
+        if (idx + 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[p] = na[p];
+    }
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc0[(2 * ft + st) * 4 + r] = c[0][ft][st][r]; if (NTILES == 2) acc1[(2 * ft + st) * 4 + r] = c[1][ft][st][r]; }
+}
+
+template <int NT, int KT, int NEXT_KIB, class Pipe, class Init, class Post>
+__device__ __forceinline__ void l16_gemm_stage3(Pipe& pipe, const float* gsrc, const float* gnext, f32x16* out, const Split3* in,
+                                                Init&& init, Post&& post) {
+    constexpr int NSP = (NT + 1) / 2;
+    lsnf_static_for<NSP>([&](auto qc) {
+        constexpr int q = decltype(qc)::value, t0 = 2 * q, cnt = (NT - t0 >= 2) ? 2 : 1;
+        const float* lb;
+        if constexpr (q + 1 < NSP) {
+            constexpr int cn = (NT - (t0 + 2) >= 2) ? 2 : 1;
+            lb = pipe.template acquire<6 * KT * cn>(gsrc + (t0 + 2) * KT * LSNF_FRAG3_FLOATS);
+        } else {
+            lb = pipe.template acquire<NEXT_KIB>(gnext);
+        }
+        out[t0] = init(t0);
+        if constexpr (cnt == 2) {
+            out[t0 + 1] = init(t0 + 1);
+            l16_panel_mma3<KT, 2>(out[t0], out[t0 + 1], in, lb, pipe.lane);
+            out[t0 + 1] = post(out[t0 + 1], t0 + 1);
+        } else {
+            l16_panel_mma3<KT, 1>(out[t0], out[t0], in, lb, pipe.lane);
+        }
+        out[t0] = post(out[t0], t0);
+    });
+}
+
+// sum over the 4 lane groups of a per-sample value (lanes n, n+16, n+32, n+48)
+__device__ __forceinline__ float l16_group_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+// relu masks of one tile in the stash's (32x32-layout) word format: lanes with g < 2 end up holding the word of
+// stash lane 16*st + n + 32*g for st = 0 / 1 (see the derivation in DESIGN.md section 4)
+__device__ __forceinline__ void l16_store_masks(unsigned* words, const f32x16& a, int n, int g) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        unsigned c = 0;
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c |= (a[(2 * ft + st) * 4 + r] > 0.0f ? 1u : 0u) << (4 * (2 * ft + (g >> 1)) + r);
+        c |= __shfl_xor(c, 32, 64);
+        if (g < 2) words[16 * st + n + 32 * g] = c;
+    }
+}
+// sigma tile of the stash ([q][lane32][4] floats, q = feature >> 3, lane32 = sample + 32*((feature >> 2) & 1))
+__device__ __forceinline__ void l16_store_sigma(float* tile_base, int t, const f32x16& sg, int n, int g) {
+    f32x4* p = reinterpret_cast<f32x4*>(tile_base + (size_t)t * 1024);
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int b = (2 * ft + st) * 4;
+            f32x4 v = {sg[b], sg[b + 1], sg[b + 2], sg[b + 3]};
+            p[(2 * ft + (g >> 1)) * 64 + 16 * st + n + 32 * (g & 1)] = v;
+        }
+}
+
+template <class C, int F3_WAVES>
+__global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3b_kernel(const Fwd3Args a) {
+    constexpr int THREADS = 64 * F3_WAVES;
+    constexpr int HT = C::HT, WT = C::WT, NZT = C::NZT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* cst = smem;
+    float* buf0 = smem + a.n_blocks * C::CONST_FLOATS;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int n = lane & 15, g = lane >> 4;
+
+    Pipe3<F3_WAVES> pipe;
+    pipe.buf0 = buf0; pipe.slot = C::SLOT3; pipe.wave = wave; pipe.lane = lane;
+    pipe.template prime<first_kib(C::P1, C::KT1)>(a.panels3);
+    for (int i = tid; i < a.n_blocks * C::CONST_FLOATS; i += THREADS) cst[i] = a.consts[i];
+
+    const long base = ((long)blockIdx.x * F3_WAVES + wave) * 32;
+    long sample[2], rows[2]; bool live[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) { sample[st] = base + 16 * st + n; live[st] = sample[st] < a.B; rows[st] = live[st] ? sample[st] : (long)a.B - 1; }
+
+    f32x16 x[NZT];
+#pragma unroll
+    for (int t = 0; t < NZT; ++t) x[t] = l16_load_tile<HT>(t, a.z_in, rows, a.nz, a.half, g, a.vec4);
+    float ell[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) ell[st] = a.objective ? a.objective[rows[st]] : 0.0f;
+
+    const LsnfActLayout al = lsnf_act_layout(a.B, HT, WT);
+    const size_t wtile = (size_t)blockIdx.x * F3_WAVES + wave;
+    for (int blk = 0; blk < a.n_blocks; ++blk) {
+        float* act = (a.act_saved && wtile * 32 < (size_t)a.B)
+                         ? a.act_saved + (size_t)blk * al.per_block + wtile * al.per_tile : nullptr;
+        const float* cb = cst + blk * C::CONST_FLOATS;
+        const float* gblk = a.panels3 + (size_t)blk * C::BLOCK3;
+        const bool more = blk + 1 < a.n_blocks;
+        const float* gnext = more ? gblk + C::BLOCK3 : nullptr;
+        auto keep = [](f32x16 acc, int) { return acc; };
+        auto relu = [](f32x16 acc, int) { return lsnf_relu16(acc); };
+
+        // ---- S1: v = Wa^T x + ca  (model.py:244,268,187) ----
+        f32x16 v[NZT];
+        {
+            Split3 xs[2 * NZT];
+            l16_split_tiles<NZT>(x, xs);
+            l16_gemm_stage3<C::P1, C::KT1, first_kib(C::P2, C::KT2)>(
+                pipe, gblk, gblk + C::OFF3_S2, v, xs, [&](int t) { return l16_bias_init(cb + 32 * t, g); }, keep);
+        }
+        if (!more) {             // last block: the v1 half is final (model.py:422) -- store it under the MFMAs of S2..S4
+#pragma unroll
+            for (int t = 0; t < HT; ++t) l16_store_tile<HT>(t, v[t], a.z_out, sample, live, a.nz, a.half, g, a.vec4);
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) { ell[st] = ell[st] + cb[32 * C::NP + 0]; ell[st] = ell[st] + cb[32 * C::NP + 1]; }
+        // ---- S2: h1 = relu(actnorm(v1 @ W1))  (model.py:326-328,307) ----
+        f32x16 h1[WT];
+        {
+            Split3 vs[2 * HT];
+            l16_split_tiles<HT>(v, vs);
+            l16_gemm_stage3<C::P2, C::KT2, first_kib(C::P3, C::KT3)>(
+                pipe, gblk + C::OFF3_S2, gblk + C::OFF3_S3, h1, vs,
+                [&](int t) { return l16_bias_init(cb + 32 * (C::P1 + t), g); }, relu);
+        }
+        if (act) {
+#pragma unroll
+            for (int t = 0; t < WT; ++t) l16_store_masks(reinterpret_cast<unsigned*>(act + al.mask_off) + t * 64, h1[t], n, g);
+        }
+        // ---- S3: h2 = relu(actnorm(h1 @ W2))  (model.py:326-328,308) ----
+        f32x16 h2[WT];
+        {
+            Split3 hs[2 * WT];
+            l16_split_tiles<WT>(h1, hs);
+            l16_gemm_stage3<C::P3, C::KT3, first_kib(C::P4, C::KT4)>(
+                pipe, gblk + C::OFF3_S3, gblk + C::OFF3_S4, h2, hs,
+                [&](int t) { return l16_bias_init(cb + 32 * (C::P1 + C::P2 + t), g); }, relu);
+        }
+        if (act) {
+#pragma unroll
+            for (int t = 0; t < WT; ++t) l16_store_masks(reinterpret_cast<unsigned*>(act + al.mask_off) + (WT + t) * 64, h2[t], n, g);
+        }
+        // ---- S4: shift t / pre-sigmoid p = fc_zeros(h2), de-interleaved (model.py:347-349,411-413) ----
+        f32x16 tp[2 * HT];
+        {
+            Split3 hs[2 * WT];
+            l16_split_tiles<WT>(h2, hs);
+            l16_gemm_stage3<C::P4, C::KT4, first_kib(C::P1, C::KT1)>(
+                pipe, gblk + C::OFF3_S4, gnext, tp, hs,
+                [&](int t) { return l16_bias_init(cb + 32 * (C::P1 + C::P2 + C::P3 + t), g); }, keep);
+        }
+        // ---- coupling + per-sample log-scale reduction (model.py:414-418), concat (:422) ----
+        float lsum[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+            x[t] = v[t];
+            f32x16 sg;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sig, l2;
+                lsnf_sigmoid_log2(tp[HT + t][r], sig, l2);
+                x[HT + t][r] = (v[HT + t][r] + tp[t][r]) * sig;
+                sg[r] = sig;
+                lsum[(r >> 2) & 1] += l2;                      // register (2*ft + st)*4 + r': sample tile st = bit 2
+            }
+            if (act) l16_store_sigma(act, t, sg, n, g);
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) ell[st] = ell[st] + -0.6931471805599453f * l16_group_sum(lsum[st]);
+        if (a.z_saved != nullptr && more) {
+#pragma unroll
+            for (int t = 0; t < NZT; ++t)
+                l16_store_tile<HT>(t, x[t], a.z_saved + (size_t)blk * a.B * a.nz, sample, live, a.nz, a.half, g, a.vec4);
+        }
+    }
+
+    // ---- epilogue: z_out, logdet, ll = -0.5*sum z^2 + log(2pi) + logdet (train.py:317-319) ----
+    float ss[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int t = 0; t < NZT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ss[(r >> 2) & 1] += x[t][r] * x[t][r];
+#pragma unroll
+    for (int t = HT; t < NZT; ++t) l16_store_tile<HT>(t, x[t], a.z_out, sample, live, a.nz, a.half, g, a.vec4);
+    float ll[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        ll[st] = (-0.5f * l16_group_sum(ss[st]) + 1.8378770664093453f) + ell[st];
+        if (live[st] && g == 0) {
+            a.logdet_out[sample[st]] = ell[st];
+            if (a.ll_out) a.ll_out[sample[st]] = ll[st];
+        }
+    }
+    if (a.stats) {   // kernel-uniform: batch sums of ll and logdet, one pair of fp64 atomics per workgroup
+        double dl = 0.0, dd = 0.0;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+            if (live[st] && g == 0) { dl += (double)ll[st]; dd += (double)ell[st]; }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { dl += __shfl_xor(dl, o, 64); dd += __shfl_xor(dd, o, 64); }
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(buf0);
+        if (lane == 0) { red[2 * wave] = dl; red[2 * wave + 1] = dd; }
+        __syncthreads();
+        if (tid == 0) {
+            double tl = 0.0, td = 0.0;
+            for (int w = 0; w < F3_WAVES; ++w) { tl += red[2 * w]; td += red[2 * w + 1]; }
+            lsnf_publish_stats(a.stats, tl, td, a.B);
+        }
+    }
+}
+
 template <class C, int F3_WAVES>
 hipError_t launch_fwd3_w(const Fwd3Args& a, hipStream_t stream) {
     const size_t lds = ((size_t)a.n_blocks * C::CONST_FLOATS + 2 * (size_t)C::SLOT3) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = lsnf_fwd3_kernel<C, F3_WAVES>;
-    static unsigned long long lds_ok = 0;
-    if (hipError_t e = lsnf_allow_big_lds((const void*)kern, &lds_ok); e != hipSuccess) return e;
+    auto kern = a.shape16 ? lsnf_fwd3b_kernel<C, F3_WAVES> : lsnf_fwd3_kernel<C, F3_WAVES>;
+    static unsigned long long lds_ok[2] = {0, 0};
+    if (hipError_t e = lsnf_allow_big_lds((const void*)kern, &lds_ok[a.shape16 ? 1 : 0]); e != hipSuccess) return e;
     const unsigned grid = (unsigned)((a.B + 32 * F3_WAVES - 1) / (32 * F3_WAVES));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * F3_WAVES), lds, stream, a);
     return hipGetLastError();
@@ -384,12 +731,13 @@ hipError_t launch_fwd3(const Fwd3Args& a, hipStream_t stream) {
 hipError_t lsnf_launch_forward3(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                 const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                 float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
-                                hipStream_t stream) {
+                                int shape16, hipStream_t stream) {
     Fwd3Args a;
+    a.shape16 = shape16;
     a.stats = stats;
     a.act_saved = act_saved ? act_saved + (size_t)first_block * lsnf_act_layout(B, g.HT, g.WT).per_block : nullptr;
     a.consts = plan + g.off_fwd_const + (size_t)first_block * g.fwd_const_floats;
-    a.panels3 = plan + g.off_f3_panels + (size_t)first_block * g.f3_block_floats;
+    a.panels3 = plan + (shape16 ? g.off_f3b_panels : g.off_f3_panels) + (size_t)first_block * g.f3_block_floats;
     a.z_in = z_in; a.objective = objective; a.z_out = z_out; a.logdet_out = logdet_out; a.ll_out = ll_out;
     a.z_saved = z_saved; a.B = B; a.nz = g.nz; a.half = g.half; a.n_blocks = n_blocks; a.vec4 = vec4;
     a.stamps = nullptr;

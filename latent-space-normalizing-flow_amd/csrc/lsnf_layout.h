@@ -28,6 +28,13 @@
 // i.e. k-slot j of lane-half h in k-step s is accumulator register 8*s + j of that lane-half -- an output tile
 // converted to bf16 pairs in register order is directly the next GEMM's B operand.
 #define LSNF_FRAG3_FLOATS 1536 /* 2 k-steps x 3 parts x 1 KiB, in 4-byte units */
+// The same three bf16 matrices once more in the A-operand order of v_mfma_f32_16x16x32_bf16 (lsnf_fwd3.hip, 16x16 variant;
+// that shape sustains a higher clock on real data).  Lane layout of that variant: a wave's 32 samples are two sample
+// tiles st of 16, lane = (n = lane & 15 -> sample 16*st + n, g = lane >> 4); a 32-feature activation tile is 16 registers
+// per lane, register (2*ft + st)*4 + r holding feature 16*ft + 4*g + r of sample 16*st + n.  Per (nt,kt) block:
+//   dword[((ft*3 + part)*64 + lane)*4 + jw] = pack(bf16 part of M[k(2jw)][n], M[k(2jw+1)][n]),  n = 32*nt + 16*ft + (lane&15),
+//   k(j) = 32*kt + (j < 4 ? 4*(lane>>4) + j : 16 + 4*(lane>>4) + j - 4)       (j = 0..7)
+// i.e. k-slots 0..3 / 4..7 of lane group g are registers r = 0..3 of the ft = 0 / 1 accumulators of that lane.
 
 struct LsnfGeo {
     int nz, half, width, depth, coupling;
@@ -47,6 +54,7 @@ struct LsnfGeo {
     size_t off_winv;            // depth * nz*nz fp32 W^-1 (natural layout; used by d log|det W|/dW)
     int f3_block_floats;        // split-bf16 forward panels per block (same tile order as the forward stream)
     size_t off_f3_panels;
+    size_t off_f3b_panels;      // the same in the 16x16x32 operand order (same size)
     size_t total_floats;
 };
 
@@ -120,6 +128,8 @@ static inline int lsnf_geo_init(LsnfGeo* g, int nz, int width, int depth, int co
     o = (o + 255) & ~(size_t)255;
     g->f3_block_floats = LSNF_FRAG3_FLOATS * (NZT * NZT + WT * HT + WT * WT + 2 * HT * WT);
     g->off_f3_panels = o;  o += (size_t)depth * g->f3_block_floats;
+    o = (o + 255) & ~(size_t)255;
+    g->off_f3b_panels = o; o += (size_t)depth * g->f3_block_floats;
     o = (o + 255) & ~(size_t)255;
     g->total_floats = o;
     return 0;

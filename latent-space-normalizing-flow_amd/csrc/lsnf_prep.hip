@@ -249,6 +249,19 @@ __device__ static inline void frag3_decode(int q, int KT, int* k0, int* k1, int*
     *k1 = 32 * kt + 16 * s + (j1 & 3) + 8 * (j1 >> 2) + 4 * h;
     *n = 32 * nt + (lane & 31);
 }
+// the same for the 16x16x32 operand order (lsnf_layout.h)
+__device__ static inline void frag3b_decode(int q, int KT, int* k0, int* k1, int* n, int* part) {
+    const int per_panel = KT * LSNF_FRAG3_FLOATS;
+    const int nt = q / per_panel; int r = q % per_panel;
+    const int kt = r / LSNF_FRAG3_FLOATS; r %= LSNF_FRAG3_FLOATS;
+    const int fp = r / 256; r %= 256;                 // ft*3 + part
+    const int ft = fp / 3, lane = r / 4, jw = r % 4;
+    *part = fp % 3;
+    const int j0 = 2 * jw, j1 = 2 * jw + 1, kg = lane >> 4;
+    *k0 = 32 * kt + (j0 < 4 ? 4 * kg + j0 : 16 + 4 * kg + j0 - 4);
+    *k1 = 32 * kt + (j1 < 4 ? 4 * kg + j1 : 16 + 4 * kg + j1 - 4);
+    *n = 32 * nt + 16 * ft + (lane & 15);
+}
 // round-to-nearest-even bf16 of a float, as its 16-bit pattern (finite inputs)
 __device__ static inline unsigned bf16_rne_bits(float x) {
     const unsigned u = __float_as_uint(x);
@@ -278,7 +291,7 @@ __global__ __launch_bounds__(256) void lsnf_pack_kernel(LsnfParamPtrs pp, LsnfGe
     const int n_fc = g.fwd_const_floats, n_fp = g.fwd_block_floats;
     const int n_ic = g.inv_const_floats, n_ip = g.inv_block_floats;
     const int n_bp = g.bwd_block_floats, n_wi = nz * nz, n_f3 = g.f3_block_floats;
-    const int total = n_fc + n_fp + n_ic + n_ip + n_bp + n_wi + n_f3;
+    const int total = n_fc + n_fp + n_ic + n_ip + n_bp + n_wi + 2 * n_f3;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
         int q = idx;
         if (q < n_fc) {                     // ---- forward constants
@@ -344,15 +357,17 @@ __global__ __launch_bounds__(256) void lsnf_pack_kernel(LsnfParamPtrs pp, LsnfGe
         q -= n_bp;
         if (q < n_wi) { plan[g.off_winv + (size_t)blk * n_wi + q] = (float)sb[q]; continue; }   // W^-1, natural layout
         q -= n_wi;
-        {                                   // ---- split-bf16 forward panels (same matrices as the forward stream)
-            unsigned* dst = reinterpret_cast<unsigned*>(plan + g.off_f3_panels + (size_t)blk * n_f3);
+        {                                   // ---- split-bf16 forward panels (same matrices as the forward stream), both operand orders
+            const bool shape16 = q >= n_f3;
+            if (shape16) q -= n_f3;
+            unsigned* dst = reinterpret_cast<unsigned*>(plan + (shape16 ? g.off_f3b_panels : g.off_f3_panels) + (size_t)blk * n_f3);
             int r = q, k0, k1, n, part, stage, KT;
             const int s1 = LSNF_FRAG3_FLOATS * NZT * NZT, s2 = LSNF_FRAG3_FLOATS * WT * HT, s3 = LSNF_FRAG3_FLOATS * WT * WT;
             if (r < s1) { stage = 1; KT = NZT; }
             else if ((r -= s1) < s2) { stage = 2; KT = HT; }
             else if ((r -= s2) < s3) { stage = 3; KT = WT; }
             else { r -= s3; stage = 4; KT = WT; }
-            frag3_decode(r, KT, &k0, &k1, &n, &part);
+            if (shape16) frag3b_decode(r, KT, &k0, &k1, &n, &part); else frag3_decode(r, KT, &k0, &k1, &n, &part);
             dst[q] = bf16_part_bits(fwd_mat(g, P, stage, k0, n), part) | (bf16_part_bits(fwd_mat(g, P, stage, k1, n), part) << 16);
         }
     }
@@ -369,7 +384,7 @@ hipError_t lsnf_launch_prepare(const LsnfGeo& g, const float* const* params_host
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int per_block = g.fwd_const_floats + g.fwd_block_floats + g.inv_const_floats + g.inv_block_floats +
-                          g.bwd_block_floats + g.nz * g.nz + g.f3_block_floats;
+                          g.bwd_block_floats + g.nz * g.nz + 2 * g.f3_block_floats;
     int gx = (per_block + 255) / 256;
     if (gx > 512) gx = 512;
     hipLaunchKernelGGL(lsnf_pack_kernel, dim3(gx, g.depth), dim3(256), 0, stream, pp, g, (const double*)scratch, plan);

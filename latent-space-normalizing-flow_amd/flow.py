@@ -162,12 +162,13 @@ def set_small_batch_max(rows: int) -> int:
     return _lib.load().lsnf_set_small_batch_max(int(rows))
 
 
-MATH_FP32, MATH_BF16X3 = 0, 1
+MATH_FP32, MATH_BF16X3, MATH_BF16X3_32 = 0, 1, 2
 
 
 def set_math_mode(mode: int) -> int:
-    """Arithmetic of the throughput forward's GEMMs: MATH_FP32 (fp32 MFMA) or MATH_BF16X3 (error-free three-way bf16
-    split on the bf16 matrix pipe, fp32-class accuracy).  Returns the previous mode (mode < 0: query)."""
+    """Arithmetic of the throughput forward's GEMMs: MATH_FP32 (fp32 MFMA), MATH_BF16X3 (error-free three-way bf16
+    split on the bf16 matrix pipe, fp32-class accuracy; 16x16x32 MFMA) or MATH_BF16X3_32 (the same on the 32x32x16
+    MFMA, kept for comparison).  Returns the previous mode (mode < 0: query)."""
     return _lib.load().lsnf_set_math_mode(int(mode))
 
 
