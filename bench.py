@@ -224,12 +224,13 @@ def main():
         tflops = FLOP_PER_SAMPLE * B_PER_GPU / (kern_ms * 1e-3) / 1e12          # algorithmic (fp32-equivalent) rate
         if args.math == "bf16x3":   # the matrix pipe executes 6 bf16 MFMA flops per algorithmic flop: price THAT against the bf16 peak
             rl = {"bound": "mfma", "achieved": SPLIT_MFMA_PER_PRODUCT * tflops, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                  "frac": SPLIT_MFMA_PER_PRODUCT * tflops / PEAK_BF16_MFMA_TFLOPS, "kernel": "lsnf_fwd3_kernel<Fwd3Cfg<2,2>>",
+                  "frac": SPLIT_MFMA_PER_PRODUCT * tflops / PEAK_BF16_MFMA_TFLOPS, "kernel": "lsnf_fwd3b_kernel<Fwd3Cfg<2,2>, 8>",
                   "note": "executed bf16 MFMA flops (6 per algorithmic flop) vs the dense bf16 peak; algorithmic_tflops is "
                           "the fp32-equivalent rate, 1.0 of the fp32 MFMA peak would be 157.3.  Calibration (tools/micro/"
-                          "mfma_bf16_shapes.hip, DESIGN.md section 5): a bare loop of this MFMA shape sustains 1628 TFLOP/s on "
-                          "random operands (the chip holds 1.93 GHz under the bf16 pipe), 2274 on zeros",
-                  "bare_mfma_loop_on_random_operands_tflops": 1628.0}
+                          "mfma_bf16_shapes.hip, DESIGN.md section 5): a bare loop of this MFMA shape (16x16x32) sustains 1819 "
+                          "TFLOP/s on random operands (the chip gives clock back under the bf16 pipe: this kernel runs at "
+                          "2.0-2.2 GHz), 2234 on zeros",
+                  "bare_mfma_loop_on_random_operands_tflops": 1819.0}
         else:
             rl = {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                   "frac": tflops / PEAK_FP32_MFMA_TFLOPS, "kernel": "lsnf_fwd_kernel<FwdCfg<2,2>, 8>"}
@@ -252,7 +253,7 @@ def main():
                                        f"{REDUCE_BUCKET} evaluations per collective)") if world > 1 else "single GPU",
                        "streams": n_streams, "clock_ramp_launches_before_warmup": RAMP_LAUNCHES,
                        "prepare_ms_not_in_step": prep_ms,
-                       "math": ("bf16x3: every GEMM operand split error-free into three bf16 terms, six bf16 MFMAs per product, "
+                       "math": ("bf16x3: every GEMM operand split error-free into three bf16 terms, six bf16 MFMAs (16x16x32) per product, "
                                 "fp32 accumulation; log-prob error vs float64 equals the fp32-MFMA kernel's (tests/"
                                 "test_gpu_forward.py::test_split_bf16_is_fp32_faithful)") if args.math == "bf16x3" else "fp32 MFMA",
                        "other_math_mode": {"math": other, "kernel_ms": kern_ms_other,

@@ -570,6 +570,8 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3b_kernel(const Fwd3
     const int lane = tid & 63;
     const int n = lane & 15, g = lane >> 4;
 
+    F3_STAMP(0, "s_memtime");
+    F3_STAMP(50, "s_memrealtime");
     Pipe3<F3_WAVES> pipe;
     pipe.buf0 = buf0; pipe.slot = C::SLOT3; pipe.wave = wave; pipe.lane = lane;
     pipe.template prime<first_kib(C::P1, C::KT1)>(a.panels3);
@@ -707,6 +709,8 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3b_kernel(const Fwd3
             lsnf_publish_stats(a.stats, tl, td, a.B);
         }
     }
+    F3_STAMP(41, "s_memtime");
+    F3_STAMP(51, "s_memrealtime");
 }
 
 template <class C, int F3_WAVES>

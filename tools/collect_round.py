@@ -15,7 +15,7 @@ shutil.copy(os.path.join(R, "secondary.json"), os.path.join(P, f"{tag}_secondary
 shutil.copy(os.path.join(R, "train_configs.jsonl"), os.path.join(P, f"{tag}_train_configs.jsonl"))
 rows = list(csv.DictReader(open(os.path.join(R, "prof", "bench_kernel_trace.csv"))))
 out = {}
-for key, name in (("fwd3", "lsnf_fwd3_kernel<Fwd3Cfg<2,2>>"), ("lsnf_fwd_kernel", "lsnf_fwd_kernel<FwdCfg<2,2>, 8>")):
+for key, name in (("fwd3", "lsnf_fwd3b_kernel<Fwd3Cfg<2,2>, 8>"), ("lsnf_fwd_kernel", "lsnf_fwd_kernel<FwdCfg<2,2>, 8>")):
     rr = sorted((r for r in rows if key in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rr]
     out[name] = {"dispatches_in_trace": len(d), "kernel_only_loop_last_200_avg_us": sum(d[-200:]) / 200, "min_us": min(d[-200:]), "max_us": max(d[-200:])}
