@@ -123,7 +123,8 @@ def params_from_state_dict(sd, depth: int, device=None) -> List[torch.Tensor]:
 def forward(plan: FlowPlan, z: torch.Tensor, objective: Optional[torch.Tensor] = None, *,
             first_block: int = 0, n_blocks: Optional[int] = None, want_ll: bool = True,
             save_for_backward: bool = False, out: Optional[Tuple[torch.Tensor, ...]] = None,
-            stats: Optional[torch.Tensor] = None, act_saved: Optional[torch.Tensor] = None):
+            stats: Optional[torch.Tensor] = None, act_saved: Optional[torch.Tensor] = None,
+            z_saved_out: Optional[torch.Tensor] = None):
     """One launch: blocks [first_block, first_block+n_blocks) on (B, nz) rows.
     Returns (z_out, logdet, ll or None, z_saved or None).  model.py:473-483 + train.py:317-319.
     act_saved: optional buffer from `new_act_saved()`, filled with the sigmoid / relu-mask stash that lets
@@ -146,8 +147,8 @@ def forward(plan: FlowPlan, z: torch.Tensor, objective: Optional[torch.Tensor] =
         z_out = torch.empty_like(z)
         logdet = torch.empty(B, dtype=torch.float32, device=z.device)
         ll = torch.empty(B, dtype=torch.float32, device=z.device) if want_ll else None
-    saved = None
-    if save_for_backward and n_blocks > 1:
+    saved = z_saved_out                     # caller-owned (n_blocks-1, B, nz) buffer for the block outputs, or
+    if saved is None and save_for_backward and n_blocks > 1:
         saved = torch.empty((n_blocks - 1, B, plan.nz), dtype=torch.float32, device=z.device)
     with torch.cuda.device(z.device):
         rc = lib.lsnf_forward(_ptr(plan.buf), plan.nz, plan.width, plan.depth, plan.coupling, first_block, n_blocks, B,
@@ -243,11 +244,14 @@ class PhiloxNoise:
 
 
 def langevin_step(plan: FlowPlan, z: torch.Tensor, grad_g: Optional[torch.Tensor], noise,
-                  step_size: float, *, inplace: bool = False, want_norms: bool = True):
+                  step_size: float, *, inplace: bool = False, want_norms: bool = True, reuse_buffers: bool = False):
     """One flow-prior Langevin update (train.py:316-329) in two launches: forward (keeps block outputs) and the
     fused backward+update.  `noise`: None, a (B, nz) tensor of N(0,1) draws, or a `PhiloxNoise` (drawn inside the
     kernel).  Returns (z_new, ll, gf_norm, gg_norm); ll is the log-prob of the INPUT z
-    (f_log_lkhd = -ll.sum(), train.py:320)."""
+    (f_log_lkhd = -ll.sum(), train.py:320).  reuse_buffers: keep the intermediate buffers (block outputs, activation stash,
+    z1, logdet, ll, norms: ~4 KB per row) on the plan between calls of the same batch size instead of asking the
+    allocator for them every step -- the returned ll / norms are then overwritten by the next call (the K-step sampler
+    consumes them at once)."""
     lib = _lib.load()
     _need_cuda(z, "z")
     B = z.shape[0]
@@ -263,11 +267,22 @@ def langevin_step(plan: FlowPlan, z: torch.Tensor, grad_g: Optional[torch.Tensor
             _need_cuda(t, name)
             if t.shape != z.shape:
                 raise LsnfError(f"{name} must have the shape of z")
-    act = new_act_saved(plan, B, z.device)
-    z1, logdet, ll, saved = forward(plan, z, None, want_ll=True, save_for_backward=True, act_saved=act)
+    cache = plan.__dict__.setdefault("_langevin_buffers", {}) if reuse_buffers else None
+    key = (B, z.device)
+    bufs = cache.get(key) if cache is not None else None
+    if bufs is None:
+        f32 = dict(dtype=torch.float32, device=z.device)
+        bufs = {"act": new_act_saved(plan, B, z.device), "out": (torch.empty_like(z), torch.empty(B, **f32), torch.empty(B, **f32)),
+                "saved": torch.empty((plan.depth - 1, B, plan.nz), **f32) if plan.depth > 1 else None,
+                "gf": torch.empty(B, **f32), "gg": torch.empty(B, **f32)}
+        if cache is not None:
+            cache.clear()                    # one batch size at a time
+            cache[key] = bufs
+    act, saved = bufs["act"], bufs["saved"]
+    z1, logdet, ll, _ = forward(plan, z, None, want_ll=True, out=bufs["out"], act_saved=act, z_saved_out=saved)
     z_new = z if inplace else torch.empty_like(z)
-    gf = torch.empty(B, dtype=torch.float32, device=z.device) if want_norms else None
-    gg = torch.empty(B, dtype=torch.float32, device=z.device) if (want_norms and grad_g is not None) else None
+    gf = bufs["gf"] if want_norms else None
+    gg = bufs["gg"] if (want_norms and grad_g is not None) else None
     with torch.cuda.device(z.device):
         rc = lib.lsnf_langevin_step(_ptr(plan.buf), plan.nz, plan.width, plan.depth, plan.coupling, B,
                                     _ptr(z), _ptr(z1), _ptr(saved), _ptr(act), _ptr(grad_g), _ptr(noise), rng,

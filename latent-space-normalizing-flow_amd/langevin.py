@@ -36,7 +36,8 @@ def sample_langevin_post_z_with_flow(z, x, netG: nn.Module, netF, *, g_l_steps: 
         if g_l_with_noise:                                                                   # train.py:325-326
             noise = philox.step(k) if philox is not None else \
                 torch.randn(z2d.shape, device=z2d.device, dtype=z2d.dtype, generator=generator)
-        z_new, ll, gf, gg = netF.langevin_step(z2d, z_grad_g.reshape(B, nz), noise, g_l_step_size)   # :316-326
+        z_new, ll, gf, gg = netF.langevin_step(z2d, z_grad_g.reshape(B, nz), noise, g_l_step_size,    # :316-326
+                                               reuse_buffers=True)
         f_log_lkhd = -ll.sum()                                                               # train.py:320
         gg_norm, gf_norm = gg.mean(), gf.mean()                                              # train.py:328-329
         z = z_new.view(B, nz, 1, 1)

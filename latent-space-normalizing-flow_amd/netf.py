@@ -263,7 +263,7 @@ class _netF(nn.Module):
         g = flow.backward_z(plan, z1, saved, ll_scale=scale, act_saved=act)
         return ll, g
 
-    def langevin_step(self, z, grad_g=None, noise=None, step_size=0.1, inplace=False):
+    def langevin_step(self, z, grad_g=None, noise=None, step_size=0.1, inplace=False, reuse_buffers=False):
         """z <- z - 0.5 s^2 (grad_g + d(-sum ll)/dz) + s*noise (train.py:316-326), flow part fused into two launches.
         noise: None, a tensor of N(0,1) draws, or a `flow.PhiloxNoise` (drawn inside the kernel).
         Returns (z_new, ll_of_input_z, |grad_f| per row, |grad_g| per row or None)."""
@@ -271,7 +271,7 @@ class _netF(nn.Module):
             noise = noise.detach().contiguous()
         return flow.langevin_step(self._plan(), z.detach().contiguous(),
                                   None if grad_g is None else grad_g.detach().contiguous(), noise, step_size,
-                                  inplace=inplace)
+                                  inplace=inplace, reuse_buffers=reuse_buffers)
 
     def mle_grads(self, z, accumulate: bool = False, max_norm: Optional[float] = None):
         """Fused flow-MLE gradients (train.py:404-411): loss_f = -mean_b ll(z_b) and d loss_f / d theta written to

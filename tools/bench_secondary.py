@@ -7,14 +7,20 @@ import lsnf_amd
 
 dev = torch.device("cuda:0")
 
-def timeit(fn, n=200, warm=20):
+def timeit(fn, n=200, warm=20, chunks=5):
+    """Median over `chunks` event-timed runs of n/chunks calls each (a single host hiccup -- GC, allocator, another
+    tenant of the box -- otherwise lands in a 100-us average as +100 us)."""
     for _ in range(warm): fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n): fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3   # us
+    per = max(1, n // chunks)
+    res = []
+    for _ in range(chunks):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(per): fn()
+        e1.record(); torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1) / per * 1e3)   # us
+    return sorted(res)[len(res) // 2]
 
 def make(nz, w, seed=1):
     hps = types.SimpleNamespace(f_n_levels=1, f_depth=5, f_flow_permutation=2, f_width=w, f_flow_coupling=1)
@@ -49,7 +55,7 @@ for (tag, nz, w, B) in [("C2/C4 SVHN/CelebA nz=100 w=64 B=100", 100, 64, 100), (
     act = lsnf_amd.flow.new_act_saved(plan, B, dev)
     r["forward_saving_with_act_stash_us"] = timeit(lambda: lsnf_amd.forward(plan, z, save_for_backward=True, act_saved=act), n)
     r["backward_z_from_act_stash_us"] = timeit(lambda: lsnf_amd.backward_z(plan, z1, saved, ll_scale=-1.0, act_saved=act), n)
-    r["langevin_step_fwd_plus_fused_update_us"] = timeit(lambda: net.langevin_step(z, gg, noise, 0.1), n)
+    r["langevin_step_fwd_plus_fused_update_us"] = timeit(lambda: net.langevin_step(z, gg, noise, 0.1, reuse_buffers=True), n)
     r["reverse_us"] = timeit(lambda: lsnf_amd.reverse(plan, z), n)
     def mle():
         net.zero_grad(set_to_none=True)
