@@ -145,7 +145,7 @@ def main():
     z1, logdet, ll = outs[0]
     # one collective per REDUCE_BUCKET evaluations of a stream (each evaluation's sums travel, bucketed): the forward
     # kernels fill the chip exactly (one workgroup per CU), so every collective kernel delays one of their workgroups
-    REDUCE_BUCKET = 8
+    REDUCE_BUCKET = 32
     reducers = [parallel.PipelinedStatsReducer(dev, bucket=REDUCE_BUCKET) for _ in range(n_streams)]
     counter = [0]
     torch.cuda.synchronize()
