@@ -61,19 +61,17 @@ const char* lsnf_last_error(void);
 
 /* Tuning knob: batches of at most `rows` rows run on the small-batch (latency) kernels, larger ones on the
  * throughput kernels; both compute the same function (results agree to fp32 rounding, not bit for bit).
- * rows < 0 only queries.  Returns the previous value (default 16384, or the LSNF_SMALL_MAX environment variable).
- * In the LSNF_MATH_BF16X3 mode the FORWARD switches at min(rows, 8192): its throughput kernel overtakes the latency
- * kernel earlier. */
+ * rows < 0 only queries.  Returns the previous value (default 16384, or the LSNF_SMALL_MAX environment variable). */
 int lsnf_set_small_batch_max(int rows);
 
-/* Arithmetic of the GEMMs in the throughput forward kernel (batches above the small-batch threshold):
+/* Arithmetic of the GEMMs in the forward kernels (both families; the backward / reverse kernels are fp32 MFMA):
  *   LSNF_MATH_FP32   : fp32 MFMA (v_mfma_f32_32x32x2_f32)
  *   LSNF_MATH_BF16X3 : both operands split error-free into three bf16 terms, six bf16 MFMAs per product with fp32
  *                      accumulation (csrc/lsnf_fwd3.hip, on v_mfma_f32_16x16x32_bf16).  Same accuracy class as fp32
  *                      MFMA (dropped terms are <= 2^-26 |w||x|); results agree with LSNF_MATH_FP32 to fp32 rounding,
  *                      not bit for bit.
- *   LSNF_MATH_BF16X3_32 : the same scheme on v_mfma_f32_32x32x16_bf16 (kept for comparison: that shape sustains a lower
- *                      clock on real data, ~8 % slower).
+ *   LSNF_MATH_BF16X3_32 : the same scheme on v_mfma_f32_32x32x16_bf16 in the throughput forward (kept for comparison:
+ *                      that shape sustains a lower clock on real data, ~8 % slower); latency forward as LSNF_MATH_FP32.
  * mode < 0 only queries.  Returns the previous mode (default LSNF_MATH_DEFAULT, or the LSNF_MATH environment
  * variable "fp32" / "bf16x3" / "bf16x3_32"). */
 #define LSNF_MATH_FP32 0

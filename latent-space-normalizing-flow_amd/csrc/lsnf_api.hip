@@ -25,6 +25,10 @@ hipError_t lsnf_launch_forward3(const LsnfGeo& g, const float* plan, int first_b
                                 const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                 float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
                                 int shape16, hipStream_t stream);
+hipError_t lsnf_launch_small3_forward(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
+                                      const float* z_in, const float* objective, float* z_out, float* logdet_out,
+                                      float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
+                                      hipStream_t stream);
 hipError_t lsnf_launch_small_forward(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                      const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                      float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
@@ -79,7 +83,6 @@ int small_batch_max() {
     return g_small_max;
 }
 
-#define LSNF_F3_CROSSOVER 8192
 // arithmetic of the throughput forward's GEMMs (LSNF_MATH=fp32|bf16x3 overrides the default)
 int g_math = -1;
 int math_mode() {
@@ -178,16 +181,16 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
     // batch-size dispatch: latency kernel (32 rows per workgroup, stages split over the 4 waves) below the
     // crossover, throughput kernel (128 rows per workgroup, weights shared through LDS) above it
     hipError_t e;
-    // the bf16x3 throughput forward overtakes the latency forward earlier (measured: 8 192 rows 35 vs 55 us, 12 288 rows
-    // 66 vs 56 us) than the fp32 throughput kernels do (~20 K rows), so in that mode the forward switches at
-    // min(small_batch_max, LSNF_F3_CROSSOVER); the backward / reverse keep small_batch_max (the activation stash and
-    // z_saved are family-independent, so a throughput forward may feed a latency backward)
     const bool split = math_mode() == LSNF_MATH_BF16X3 || math_mode() == LSNF_MATH_BF16X3_32;
-    const int fwd_small_max = (split && small_batch_max() > LSNF_F3_CROSSOVER) ? LSNF_F3_CROSSOVER
-                                                                                                         : small_batch_max();
+    const int fwd_small_max = small_batch_max();
     if (B <= fwd_small_max) {
-        e = lsnf_launch_small_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
-                                      z_saved, act_saved, stats, vec4, (hipStream_t)stream);
+        e = hipErrorInvalidValue;
+        if (math_mode() == LSNF_MATH_BF16X3)      // latency forward on the bf16 pipe: 16-sample workgroups (lsnf_small3_fwd.hip)
+            e = lsnf_launch_small3_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
+                                           z_saved, act_saved, stats, vec4, (hipStream_t)stream);
+        if (e == hipErrorInvalidValue)
+            e = lsnf_launch_small_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
+                                          z_saved, act_saved, stats, vec4, (hipStream_t)stream);
     } else {
         e = hipErrorInvalidValue;
         if (split)                                // error-free split on the bf16 matrix pipe (lsnf_fwd3.hip)

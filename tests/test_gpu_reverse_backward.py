@@ -157,10 +157,10 @@ def test_full_size_backward_properties(lsnf, gpu_device):
     same_up_to_kinks(gc, g[:B2])
 
 
-def test_throughput_forward_feeds_latency_backward(lsnf, gpu_device):
-    """Default dispatch at 10 000 rows: the bf16x3 throughput forward (above its 8 192-row crossover) writes z_saved and
-    the activation stash, the latency backward (below the 16 384-row threshold) reads them -- the two layouts are
-    family-independent."""
+def test_default_dispatch_mid_size_batch(lsnf, gpu_device):
+    """Default dispatch at 10 000 rows: the bf16x3 latency forward (16-sample workgroups, L16 lane layout) writes z_saved
+    and the activation stash, the fp32 latency backward (32-sample workgroups, 32x32 layout) reads them -- what travels
+    through HBM is layout-independent."""
     nz, width, depth, B = 100, 64, 5, 10000
     p = O.init_params(nz, width, depth, seed=5)
     plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)

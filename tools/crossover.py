@@ -17,7 +17,7 @@ which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 for B in (32, 100, 256, 1024, 4096, 8192, 12288, 16384, 20480, 24576, 32768, 49152, 65536):
     z = torch.randn(B, 128, device=dev)
     res = []
-    for name, thr, math in (("latency", 1 << 30, 0), ("throughput", 0, 1), ("throughput fp32", 0, 0)):
+    for name, thr, math in (("latency", 1 << 30, 0), ("throughput", 0, 1), ("throughput fp32", 0, 0), ("latency bf16x3", 1 << 30, 1)):
         lsnf_amd.flow.set_small_batch_max(thr)
         lsnf_amd.flow.set_math_mode(math)
         if which == "fwd":
@@ -26,4 +26,4 @@ for B in (32, 100, 256, 1024, 4096, 8192, 12288, 16384, 20480, 24576, 32768, 491
             z1, ld, ll, sv = lsnf_amd.forward(plan, z, save_for_backward=True)
             t = timeit(lambda: lsnf_amd.backward_z(plan, z1, sv, ll_scale=-1.0), 100)
         res.append(t)
-    print(f"{which} B={B:6d}  latency-kernel {res[0]:8.1f} us   throughput-kernel bf16x3 {res[1]:8.1f} us   fp32 MFMA {res[2]:8.1f} us")
+    print(f"{which} B={B:6d}  latency-kernel {res[0]:8.1f} us   throughput-kernel bf16x3 {res[1]:8.1f} us   fp32 MFMA {res[2]:8.1f} us   latency-kernel bf16x3 (16-sample workgroups; above 8192 rows = throughput) {res[3]:8.1f} us")
