@@ -45,6 +45,9 @@ hipError_t lsnf_launch_small_backward_z(const LsnfGeo& g, const float* plan, int
                                         const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale, float* g_z_in,
                                         int vec4, hipStream_t stream, const LsnfLangevinArgs* lv, const float* act_saved,
                                         float* dump = nullptr, float* gl_total = nullptr);
+hipError_t lsnf_launch_small3_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
+                                         const float* act_saved, const float* g_z1, const float* g_logdet, int ll_mode,
+                                         float ll_scale, float* g_z_in, int vec4, hipStream_t stream, const LsnfLangevinArgs* lv);
 hipError_t lsnf_launch_backward_params(const LsnfGeo& g, const float* plan, const float* const* params_host,
                                        float* const* grads_host, int B, const float* z_in, const float* z_out,
                                        const float* z_saved, const float* g_z1, const float* g_logdet, int ll_mode,
@@ -243,11 +246,18 @@ int lsnf_backward_z(const float* plan, int nz, int width, int depth, int couplin
     if (B == 0) return LSNF_OK;
     const int vec4 = row_vector_width(g, {z_out, g_z_in, z_saved, g_z1});
     if (act_saved && !aligned16(act_saved)) return fail(LSNF_E_ARG, "lsnf_backward_z: act_saved must be 16-byte aligned");
-    hipError_t e = (B <= small_batch_max())
-        ? lsnf_launch_small_backward_z(g, plan, B, z_out, z_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, vec4,
-                                       (hipStream_t)stream, nullptr, act_saved)
-        : lsnf_launch_backward_z(g, plan, B, z_out, z_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, nullptr,
-                                 nullptr, vec4, (hipStream_t)stream, nullptr, act_saved);
+    hipError_t e = hipErrorInvalidValue;
+    if (B <= small_batch_max()) {
+        if (act_saved && math_mode() == LSNF_MATH_BF16X3)     // from the stash, on the bf16 pipe (lsnf_small3_bwd.hip)
+            e = lsnf_launch_small3_backward_z(g, plan, B, z_out, z_saved, act_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in,
+                                              vec4, (hipStream_t)stream, nullptr);
+        if (e == hipErrorInvalidValue)
+            e = lsnf_launch_small_backward_z(g, plan, B, z_out, z_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, vec4,
+                                             (hipStream_t)stream, nullptr, act_saved);
+    } else {
+        e = lsnf_launch_backward_z(g, plan, B, z_out, z_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, nullptr,
+                                   nullptr, vec4, (hipStream_t)stream, nullptr, act_saved);
+    }
     if (e != hipSuccess) return hip_fail(e, "lsnf_backward_z launch");
     return LSNF_OK;
 }
@@ -273,11 +283,18 @@ int lsnf_langevin_step(const float* plan, int nz, int width, int depth, int coup
     LsnfLangevinArgs lv = {z_cur, grad_g, noise, z_new, gf_norm, gg_norm, step_size,
                            rng ? LsnfRngArgs{rng->seed, rng->offset, rng->offset_dev, rng->row0, 1}
                                : LsnfRngArgs{0ull, 0ull, nullptr, 0ll, 0}};
-    hipError_t e = (B <= small_batch_max())
-        ? lsnf_launch_small_backward_z(g, plan, B, z_out, z_saved, nullptr, nullptr, /*ll_mode=*/1, /*ll_scale=*/-1.0f,
-                                       nullptr, vec4, (hipStream_t)stream, &lv, act_saved)
-        : lsnf_launch_backward_z(g, plan, B, z_out, z_saved, nullptr, nullptr, /*ll_mode=*/1, /*ll_scale=*/-1.0f,
-                                 nullptr, nullptr, nullptr, vec4, (hipStream_t)stream, &lv, act_saved);
+    hipError_t e = hipErrorInvalidValue;
+    if (B <= small_batch_max()) {
+        if (act_saved && math_mode() == LSNF_MATH_BF16X3)
+            e = lsnf_launch_small3_backward_z(g, plan, B, z_out, z_saved, act_saved, nullptr, nullptr, /*ll_mode=*/1,
+                                              /*ll_scale=*/-1.0f, nullptr, vec4, (hipStream_t)stream, &lv);
+        if (e == hipErrorInvalidValue)
+            e = lsnf_launch_small_backward_z(g, plan, B, z_out, z_saved, nullptr, nullptr, /*ll_mode=*/1, /*ll_scale=*/-1.0f,
+                                             nullptr, vec4, (hipStream_t)stream, &lv, act_saved);
+    } else {
+        e = lsnf_launch_backward_z(g, plan, B, z_out, z_saved, nullptr, nullptr, /*ll_mode=*/1, /*ll_scale=*/-1.0f,
+                                   nullptr, nullptr, nullptr, vec4, (hipStream_t)stream, &lv, act_saved);
+    }
     if (e != hipSuccess) return hip_fail(e, "lsnf_langevin_step launch");
     return LSNF_OK;
 }

@@ -291,7 +291,8 @@ __global__ __launch_bounds__(256) void lsnf_pack_kernel(LsnfParamPtrs pp, LsnfGe
     const int n_fc = g.fwd_const_floats, n_fp = g.fwd_block_floats;
     const int n_ic = g.inv_const_floats, n_ip = g.inv_block_floats;
     const int n_bp = g.bwd_block_floats, n_wi = nz * nz, n_f3 = g.f3_block_floats;
-    const int total = n_fc + n_fp + n_ic + n_ip + n_bp + n_wi + 2 * n_f3;
+    const int n_b3 = g.b3_block_floats;
+    const int total = n_fc + n_fp + n_ic + n_ip + n_bp + n_wi + 2 * n_f3 + n_b3;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
         int q = idx;
         if (q < n_fc) {                     // ---- forward constants
@@ -357,6 +358,20 @@ __global__ __launch_bounds__(256) void lsnf_pack_kernel(LsnfParamPtrs pp, LsnfGe
         q -= n_bp;
         if (q < n_wi) { plan[g.off_winv + (size_t)blk * n_wi + q] = (float)sb[q]; continue; }   // W^-1, natural layout
         q -= n_wi;
+        if (q >= 2 * n_f3) {                // ---- split-bf16 backward panels (transposes, as the fp32 backward stream), 16x16x32 order
+            q -= 2 * n_f3;
+            unsigned* dst = reinterpret_cast<unsigned*>(plan + g.off_b3b_panels + (size_t)blk * n_b3);
+            int r = q, k0, k1, n, part;
+            const int b4 = LSNF_FRAG3_FLOATS * WT * 2 * HT, b3 = LSNF_FRAG3_FLOATS * WT * WT, b2 = LSNF_FRAG3_FLOATS * HT * WT;
+            int stage, KT;
+            if (r < b4) { stage = 4; KT = 2 * HT; }
+            else if ((r -= b4) < b3) { stage = 3; KT = WT; }
+            else if ((r -= b3) < b2) { stage = 2; KT = WT; }
+            else { r -= b2; stage = 1; KT = NZT; }
+            frag3b_decode(r, KT, &k0, &k1, &n, &part);
+            dst[q] = bf16_part_bits(fwd_mat(g, P, stage, n, k0), part) | (bf16_part_bits(fwd_mat(g, P, stage, n, k1), part) << 16);
+            continue;
+        }
         {                                   // ---- split-bf16 forward panels (same matrices as the forward stream), both operand orders
             const bool shape16 = q >= n_f3;
             if (shape16) q -= n_f3;
@@ -384,7 +399,7 @@ hipError_t lsnf_launch_prepare(const LsnfGeo& g, const float* const* params_host
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int per_block = g.fwd_const_floats + g.fwd_block_floats + g.inv_const_floats + g.inv_block_floats +
-                          g.bwd_block_floats + g.nz * g.nz + 2 * g.f3_block_floats;
+                          g.bwd_block_floats + g.nz * g.nz + 2 * g.f3_block_floats + g.b3_block_floats;
     int gx = (per_block + 255) / 256;
     if (gx > 512) gx = 512;
     hipLaunchKernelGGL(lsnf_pack_kernel, dim3(gx, g.depth), dim3(256), 0, stream, pp, g, (const double*)scratch, plan);
