@@ -39,6 +39,8 @@ hipError_t lsnf_launch_backward_z(const LsnfGeo& g, const float* plan, int B, co
                                   const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
                                   float* g_z_in, float* dump, float* gl_total, int vec4, hipStream_t stream,
                                   const LsnfLangevinArgs* lv = nullptr, const float* act_saved = nullptr);
+hipError_t lsnf_launch_small3_reverse(const LsnfGeo& g, const float* plan, int B, const float* z_in, const float* objective,
+                                      float* z_out, float* objective_out, int vec4, hipStream_t stream);
 hipError_t lsnf_launch_small_reverse(const LsnfGeo& g, const float* plan, int B, const float* z_in, const float* objective,
                                      float* z_out, float* objective_out, int vec4, hipStream_t stream);
 hipError_t lsnf_launch_small_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
@@ -225,9 +227,15 @@ int lsnf_reverse(const float* plan, int nz, int width, int depth, int coupling, 
         return fail(LSNF_E_ARG, "lsnf_reverse: tensors must be 4-byte aligned");
     if (B == 0) return LSNF_OK;
     const int vec4 = row_vector_width(g, {z_in, z_out});
-    hipError_t e = (B <= small_batch_max())
-        ? lsnf_launch_small_reverse(g, plan, B, z_in, objective, z_out, objective_out, vec4, (hipStream_t)stream)
-        : lsnf_launch_reverse(g, plan, B, z_in, objective, z_out, objective_out, vec4, (hipStream_t)stream);
+    hipError_t e = hipErrorInvalidValue;
+    if (B <= small_batch_max()) {
+        if (math_mode() == LSNF_MATH_BF16X3)      // on the bf16 pipe (lsnf_small3_rev.hip)
+            e = lsnf_launch_small3_reverse(g, plan, B, z_in, objective, z_out, objective_out, vec4, (hipStream_t)stream);
+        if (e == hipErrorInvalidValue)
+            e = lsnf_launch_small_reverse(g, plan, B, z_in, objective, z_out, objective_out, vec4, (hipStream_t)stream);
+    } else {
+        e = lsnf_launch_reverse(g, plan, B, z_in, objective, z_out, objective_out, vec4, (hipStream_t)stream);
+    }
     if (e != hipSuccess) return hip_fail(e, "lsnf_reverse launch");
     return LSNF_OK;
 }

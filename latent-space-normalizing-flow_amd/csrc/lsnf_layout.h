@@ -57,6 +57,8 @@ struct LsnfGeo {
     size_t off_f3b_panels;      // the same in the 16x16x32 operand order (same size)
     int b3_block_floats;        // backward-z panels (B4, B3, B2, B1) as three bf16 matrices, 16x16x32 operand order
     size_t off_b3b_panels;
+    int i3_block_floats;        // inverse panel I1 likewise
+    size_t off_i3b_panels;
     size_t total_floats;
 };
 
@@ -135,6 +137,9 @@ static inline int lsnf_geo_init(LsnfGeo* g, int nz, int width, int depth, int co
     o = (o + 255) & ~(size_t)255;
     g->b3_block_floats = LSNF_FRAG3_FLOATS * (WT * 2 * HT + WT * WT + HT * WT + NZT * NZT);
     g->off_b3b_panels = o; o += (size_t)depth * g->b3_block_floats;
+    o = (o + 255) & ~(size_t)255;
+    g->i3_block_floats = LSNF_FRAG3_FLOATS * (NZT * NZT);
+    g->off_i3b_panels = o; o += (size_t)depth * g->i3_block_floats;
     o = (o + 255) & ~(size_t)255;
     g->total_floats = o;
     return 0;

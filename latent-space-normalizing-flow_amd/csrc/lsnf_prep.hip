@@ -291,8 +291,8 @@ __global__ __launch_bounds__(256) void lsnf_pack_kernel(LsnfParamPtrs pp, LsnfGe
     const int n_fc = g.fwd_const_floats, n_fp = g.fwd_block_floats;
     const int n_ic = g.inv_const_floats, n_ip = g.inv_block_floats;
     const int n_bp = g.bwd_block_floats, n_wi = nz * nz, n_f3 = g.f3_block_floats;
-    const int n_b3 = g.b3_block_floats;
-    const int total = n_fc + n_fp + n_ic + n_ip + n_bp + n_wi + 2 * n_f3 + n_b3;
+    const int n_b3 = g.b3_block_floats, n_i3 = g.i3_block_floats;
+    const int total = n_fc + n_fp + n_ic + n_ip + n_bp + n_wi + 2 * n_f3 + n_b3 + n_i3;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
         int q = idx;
         if (q < n_fc) {                     // ---- forward constants
@@ -358,6 +358,21 @@ __global__ __launch_bounds__(256) void lsnf_pack_kernel(LsnfParamPtrs pp, LsnfGe
         q -= n_bp;
         if (q < n_wi) { plan[g.off_winv + (size_t)blk * n_wi + q] = (float)sb[q]; continue; }   // W^-1, natural layout
         q -= n_wi;
+        if (q >= 2 * n_f3 + n_b3) {         // ---- split-bf16 inverse panel I1: Winv' = Winv diag(exp(-3 logs_a)), 16x16x32 order
+            q -= 2 * n_f3 + n_b3;
+            unsigned* dst = reinterpret_cast<unsigned*>(plan + g.off_i3b_panels + (size_t)blk * n_i3);
+            int k0, k1, n, part;
+            frag3b_decode(q, NZT, &k0, &k1, &n, &part);
+            const SplitIdx sn = split_nat(n, HT, g.half);
+            double v[2] = {0.0, 0.0};
+            const int ks[2] = {k0, k1};
+            for (int i = 0; i < 2; ++i) {
+                const SplitIdx sk = split_nat(ks[i], HT, g.half);
+                if (sk.ok && sn.ok) v[i] = sb[(size_t)sk.nat * nz + sn.nat] * exp(-(double)(P[P_ALOGS][sn.nat] * 3.0f));
+            }
+            dst[q] = bf16_part_bits(v[0], part) | (bf16_part_bits(v[1], part) << 16);
+            continue;
+        }
         if (q >= 2 * n_f3) {                // ---- split-bf16 backward panels (transposes, as the fp32 backward stream), 16x16x32 order
             q -= 2 * n_f3;
             unsigned* dst = reinterpret_cast<unsigned*>(plan + g.off_b3b_panels + (size_t)blk * n_b3);
@@ -399,7 +414,7 @@ hipError_t lsnf_launch_prepare(const LsnfGeo& g, const float* const* params_host
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int per_block = g.fwd_const_floats + g.fwd_block_floats + g.inv_const_floats + g.inv_block_floats +
-                          g.bwd_block_floats + g.nz * g.nz + 2 * g.f3_block_floats + g.b3_block_floats;
+                          g.bwd_block_floats + g.nz * g.nz + 2 * g.f3_block_floats + g.b3_block_floats + g.i3_block_floats;
     int gx = (per_block + 255) / 256;
     if (gx > 512) gx = 512;
     hipLaunchKernelGGL(lsnf_pack_kernel, dim3(gx, g.depth), dim3(256), 0, stream, pp, g, (const double*)scratch, plan);
