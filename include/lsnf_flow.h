@@ -61,7 +61,9 @@ const char* lsnf_last_error(void);
 
 /* Tuning knob: batches of at most `rows` rows run on the small-batch (latency) kernels, larger ones on the
  * throughput kernels; both compute the same function (results agree to fp32 rounding, not bit for bit).
- * rows < 0 only queries.  Returns the previous value (default 16384, or the LSNF_SMALL_MAX environment variable). */
+ * rows < 0 only queries.  Returns the previous value (default 16384, or the LSNF_SMALL_MAX environment variable).
+ * In the LSNF_MATH_BF16X3 mode the backward-from-the-stash and the reverse stay on their (bf16) latency kernels up to
+ * 3 * rows: their throughput counterparts are still fp32 MFMA and only overtake there. */
 int lsnf_set_small_batch_max(int rows);
 
 /* Arithmetic of the GEMMs in the forward kernels (both families; the backward / reverse kernels are fp32 MFMA):

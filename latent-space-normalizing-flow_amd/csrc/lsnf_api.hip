@@ -99,6 +99,13 @@ int math_mode() {
     return g_math;
 }
 
+// The bf16x3 latency backward-from-the-stash and reverse stay ahead of their (still fp32-MFMA) throughput counterparts up
+// to ~3x the forward's crossover (measured, tools/crossover.py bwds / rev: 93 vs 103 us at 32 768 rows, 140 vs 176 at 49 152)
+int s3_bwd_max() {
+    const int m = small_batch_max();
+    return (math_mode() == LSNF_MATH_BF16X3 && m < (1 << 28)) ? 3 * m : m;
+}
+
 int geo_or_fail(LsnfGeo* g, int nz, int width, int depth, int coupling) {
     if (lsnf_geo_init(g, nz, width, depth, coupling))
         return fail(LSNF_E_GEOMETRY, "unsupported geometry nz=%d width=%d depth=%d coupling=%d "
@@ -228,14 +235,12 @@ int lsnf_reverse(const float* plan, int nz, int width, int depth, int coupling, 
     if (B == 0) return LSNF_OK;
     const int vec4 = row_vector_width(g, {z_in, z_out});
     hipError_t e = hipErrorInvalidValue;
-    if (B <= small_batch_max()) {
-        if (math_mode() == LSNF_MATH_BF16X3)      // on the bf16 pipe (lsnf_small3_rev.hip)
-            e = lsnf_launch_small3_reverse(g, plan, B, z_in, objective, z_out, objective_out, vec4, (hipStream_t)stream);
-        if (e == hipErrorInvalidValue)
-            e = lsnf_launch_small_reverse(g, plan, B, z_in, objective, z_out, objective_out, vec4, (hipStream_t)stream);
-    } else {
-        e = lsnf_launch_reverse(g, plan, B, z_in, objective, z_out, objective_out, vec4, (hipStream_t)stream);
-    }
+    if (B <= s3_bwd_max() && math_mode() == LSNF_MATH_BF16X3)      // on the bf16 pipe (lsnf_small3_rev.hip)
+        e = lsnf_launch_small3_reverse(g, plan, B, z_in, objective, z_out, objective_out, vec4, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue)      // not taken or not covered: the fp32-MFMA kernels of the batch size's family
+        e = (B <= small_batch_max())
+            ? lsnf_launch_small_reverse(g, plan, B, z_in, objective, z_out, objective_out, vec4, (hipStream_t)stream)
+            : lsnf_launch_reverse(g, plan, B, z_in, objective, z_out, objective_out, vec4, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "lsnf_reverse launch");
     return LSNF_OK;
 }
@@ -255,17 +260,15 @@ int lsnf_backward_z(const float* plan, int nz, int width, int depth, int couplin
     const int vec4 = row_vector_width(g, {z_out, g_z_in, z_saved, g_z1});
     if (act_saved && !aligned16(act_saved)) return fail(LSNF_E_ARG, "lsnf_backward_z: act_saved must be 16-byte aligned");
     hipError_t e = hipErrorInvalidValue;
-    if (B <= small_batch_max()) {
-        if (act_saved && math_mode() == LSNF_MATH_BF16X3)     // from the stash, on the bf16 pipe (lsnf_small3_bwd.hip)
-            e = lsnf_launch_small3_backward_z(g, plan, B, z_out, z_saved, act_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in,
-                                              vec4, (hipStream_t)stream, nullptr);
-        if (e == hipErrorInvalidValue)
-            e = lsnf_launch_small_backward_z(g, plan, B, z_out, z_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, vec4,
-                                             (hipStream_t)stream, nullptr, act_saved);
-    } else {
-        e = lsnf_launch_backward_z(g, plan, B, z_out, z_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, nullptr,
-                                   nullptr, vec4, (hipStream_t)stream, nullptr, act_saved);
-    }
+    if (B <= s3_bwd_max() && act_saved && math_mode() == LSNF_MATH_BF16X3)     // from the stash, on the bf16 pipe (lsnf_small3_bwd.hip)
+        e = lsnf_launch_small3_backward_z(g, plan, B, z_out, z_saved, act_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in,
+                                          vec4, (hipStream_t)stream, nullptr);
+    if (e == hipErrorInvalidValue)      // not taken or not covered: the fp32-MFMA kernels of the batch size's family
+        e = (B <= small_batch_max())
+            ? lsnf_launch_small_backward_z(g, plan, B, z_out, z_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, vec4,
+                                             (hipStream_t)stream, nullptr, act_saved)
+            : lsnf_launch_backward_z(g, plan, B, z_out, z_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, nullptr,
+                                       nullptr, vec4, (hipStream_t)stream, nullptr, act_saved);
     if (e != hipSuccess) return hip_fail(e, "lsnf_backward_z launch");
     return LSNF_OK;
 }
@@ -292,17 +295,15 @@ int lsnf_langevin_step(const float* plan, int nz, int width, int depth, int coup
                            rng ? LsnfRngArgs{rng->seed, rng->offset, rng->offset_dev, rng->row0, 1}
                                : LsnfRngArgs{0ull, 0ull, nullptr, 0ll, 0}};
     hipError_t e = hipErrorInvalidValue;
-    if (B <= small_batch_max()) {
-        if (act_saved && math_mode() == LSNF_MATH_BF16X3)
-            e = lsnf_launch_small3_backward_z(g, plan, B, z_out, z_saved, act_saved, nullptr, nullptr, /*ll_mode=*/1,
-                                              /*ll_scale=*/-1.0f, nullptr, vec4, (hipStream_t)stream, &lv);
-        if (e == hipErrorInvalidValue)
-            e = lsnf_launch_small_backward_z(g, plan, B, z_out, z_saved, nullptr, nullptr, /*ll_mode=*/1, /*ll_scale=*/-1.0f,
-                                             nullptr, vec4, (hipStream_t)stream, &lv, act_saved);
-    } else {
-        e = lsnf_launch_backward_z(g, plan, B, z_out, z_saved, nullptr, nullptr, /*ll_mode=*/1, /*ll_scale=*/-1.0f,
-                                   nullptr, nullptr, nullptr, vec4, (hipStream_t)stream, &lv, act_saved);
-    }
+    if (B <= s3_bwd_max() && act_saved && math_mode() == LSNF_MATH_BF16X3)
+        e = lsnf_launch_small3_backward_z(g, plan, B, z_out, z_saved, act_saved, nullptr, nullptr, /*ll_mode=*/1,
+                                          /*ll_scale=*/-1.0f, nullptr, vec4, (hipStream_t)stream, &lv);
+    if (e == hipErrorInvalidValue)      // not taken or not covered: the fp32-MFMA kernels of the batch size's family
+        e = (B <= small_batch_max())
+            ? lsnf_launch_small_backward_z(g, plan, B, z_out, z_saved, nullptr, nullptr, /*ll_mode=*/1, /*ll_scale=*/-1.0f,
+                                             nullptr, vec4, (hipStream_t)stream, &lv, act_saved)
+            : lsnf_launch_backward_z(g, plan, B, z_out, z_saved, nullptr, nullptr, /*ll_mode=*/1, /*ll_scale=*/-1.0f,
+                                       nullptr, nullptr, nullptr, vec4, (hipStream_t)stream, &lv, act_saved);
     if (e != hipSuccess) return hip_fail(e, "lsnf_langevin_step launch");
     return LSNF_OK;
 }

@@ -22,8 +22,11 @@ for B in (32, 100, 256, 1024, 4096, 8192, 12288, 16384, 20480, 24576, 32768, 491
         lsnf_amd.flow.set_math_mode(math)
         if which == "fwd":
             t = timeit(lambda: lsnf_amd.forward(plan, z), 300)
-        else:
-            z1, ld, ll, sv = lsnf_amd.forward(plan, z, save_for_backward=True)
-            t = timeit(lambda: lsnf_amd.backward_z(plan, z1, sv, ll_scale=-1.0), 100)
+        elif which == "rev":
+            t = timeit(lambda: lsnf_amd.reverse(plan, z), 100)
+        else:   # "bwd": recomputing backward; "bwds": backward from the activation stash
+            act = lsnf_amd.flow.new_act_saved(plan, B, dev) if which == "bwds" else None
+            z1, ld, ll, sv = lsnf_amd.forward(plan, z, save_for_backward=True, act_saved=act)
+            t = timeit(lambda: lsnf_amd.backward_z(plan, z1, sv, ll_scale=-1.0, act_saved=act), 100)
         res.append(t)
     print(f"{which} B={B:6d}  latency-kernel {res[0]:8.1f} us   throughput-kernel bf16x3 {res[1]:8.1f} us   fp32 MFMA {res[2]:8.1f} us   latency-kernel bf16x3 (16-sample workgroups; above 8192 rows = throughput) {res[3]:8.1f} us")
