@@ -66,7 +66,9 @@ const char* lsnf_last_error(void);
  * 3 * rows: their throughput counterparts are still fp32 MFMA and only overtake there. */
 int lsnf_set_small_batch_max(int rows);
 
-/* Arithmetic of the GEMMs in the forward kernels (both families; the backward / reverse kernels are fp32 MFMA):
+/* Arithmetic of the GEMMs.  Affects the forward kernels (both families) and the latency-family backward-from-the-stash
+ * and reverse; the parameter gradients, the recomputing backward and the throughput backward / reverse are fp32 MFMA
+ * in every mode:
  *   LSNF_MATH_FP32   : fp32 MFMA (v_mfma_f32_32x32x2_f32)
  *   LSNF_MATH_BF16X3 : both operands split error-free into three bf16 terms, six bf16 MFMAs per product with fp32
  *                      accumulation (csrc/lsnf_fwd3.hip, on v_mfma_f32_16x16x32_bf16).  Same accuracy class as fp32
