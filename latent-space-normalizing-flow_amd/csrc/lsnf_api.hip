@@ -50,6 +50,9 @@ hipError_t lsnf_launch_small_backward_z(const LsnfGeo& g, const float* plan, int
 hipError_t lsnf_launch_small3_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
                                          const float* act_saved, const float* g_z1, const float* g_logdet, int ll_mode,
                                          float ll_scale, float* g_z_in, int vec4, hipStream_t stream, const LsnfLangevinArgs* lv);
+hipError_t lsnf_launch_backward3_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
+                                   const float* act_saved, const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
+                                   float* g_z_in, int vec4, hipStream_t stream, const LsnfLangevinArgs* lv);
 hipError_t lsnf_launch_backward_params(const LsnfGeo& g, const float* plan, const float* const* params_host,
                                        float* const* grads_host, int B, const float* z_in, const float* z_out,
                                        const float* z_saved, const float* g_z1, const float* g_logdet, int ll_mode,
@@ -102,8 +105,10 @@ int math_mode() {
 // The bf16x3 latency backward-from-the-stash and reverse stay ahead of their (still fp32-MFMA) throughput counterparts up
 // to ~3x the forward's crossover (measured, tools/crossover.py bwds / rev: 93 vs 103 us at 32 768 rows, 140 vs 176 at 49 152)
 int s3_bwd_max() {
+    static int mult = -1;                         // LSNF_S3_BWD_MULT: developer override for crossover sweeps
+    if (mult < 0) { const char* e = getenv("LSNF_S3_BWD_MULT"); mult = e ? atoi(e) : 3; }
     const int m = small_batch_max();
-    return (math_mode() == LSNF_MATH_BF16X3 && m < (1 << 28)) ? 3 * m : m;
+    return (math_mode() == LSNF_MATH_BF16X3 && m < (1 << 28)) ? mult * m : m;
 }
 
 int geo_or_fail(LsnfGeo* g, int nz, int width, int depth, int coupling) {
@@ -263,6 +268,9 @@ int lsnf_backward_z(const float* plan, int nz, int width, int depth, int couplin
     if (B <= s3_bwd_max() && act_saved && math_mode() == LSNF_MATH_BF16X3)     // from the stash, on the bf16 pipe (lsnf_small3_bwd.hip)
         e = lsnf_launch_small3_backward_z(g, plan, B, z_out, z_saved, act_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in,
                                           vec4, (hipStream_t)stream, nullptr);
+    else if (act_saved && math_mode() == LSNF_MATH_BF16X3 && B > small_batch_max())          // throughput form (lsnf_bwd3.hip)
+        e = lsnf_launch_backward3_z(g, plan, B, z_out, z_saved, act_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, vec4,
+                                    (hipStream_t)stream, nullptr);
     if (e == hipErrorInvalidValue)      // not taken or not covered: the fp32-MFMA kernels of the batch size's family
         e = (B <= small_batch_max())
             ? lsnf_launch_small_backward_z(g, plan, B, z_out, z_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, vec4,
@@ -298,6 +306,9 @@ int lsnf_langevin_step(const float* plan, int nz, int width, int depth, int coup
     if (B <= s3_bwd_max() && act_saved && math_mode() == LSNF_MATH_BF16X3)
         e = lsnf_launch_small3_backward_z(g, plan, B, z_out, z_saved, act_saved, nullptr, nullptr, /*ll_mode=*/1,
                                           /*ll_scale=*/-1.0f, nullptr, vec4, (hipStream_t)stream, &lv);
+    else if (act_saved && math_mode() == LSNF_MATH_BF16X3 && B > small_batch_max())
+        e = lsnf_launch_backward3_z(g, plan, B, z_out, z_saved, act_saved, nullptr, nullptr, /*ll_mode=*/1, /*ll_scale=*/-1.0f,
+                                    nullptr, vec4, (hipStream_t)stream, &lv);
     if (e == hipErrorInvalidValue)      // not taken or not covered: the fp32-MFMA kernels of the batch size's family
         e = (B <= small_batch_max())
             ? lsnf_launch_small_backward_z(g, plan, B, z_out, z_saved, nullptr, nullptr, /*ll_mode=*/1, /*ll_scale=*/-1.0f,
