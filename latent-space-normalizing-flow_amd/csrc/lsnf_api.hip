@@ -102,13 +102,13 @@ int math_mode() {
     return g_math;
 }
 
-// The bf16x3 latency backward-from-the-stash and reverse stay ahead of their (still fp32-MFMA) throughput counterparts up
-// to ~3x the forward's crossover (measured, tools/crossover.py bwds / rev: 93 vs 103 us at 32 768 rows, 140 vs 176 at 49 152)
-int s3_bwd_max() {
-    static int mult = -1;                         // LSNF_S3_BWD_MULT: developer override for crossover sweeps
-    if (mult < 0) { const char* e = getenv("LSNF_S3_BWD_MULT"); mult = e ? atoi(e) : 3; }
+// The bf16x3 latency reverse is at least as fast as the (still fp32-MFMA) throughput reverse at every batch size measured
+// (tools/crossover.py rev: 91 vs 95 us at 32 768 rows, 138 vs 181 at 49 152, 173 vs 185 at 65 536), so in that mode it
+// serves all of them unless the latency kernels are switched off (threshold 0).  The backward has a bf16x3 throughput
+// form (lsnf_bwd3.hip) and crosses over where the forward does.
+int s3_rev_max() {
     const int m = small_batch_max();
-    return (math_mode() == LSNF_MATH_BF16X3 && m < (1 << 28)) ? mult * m : m;
+    return (math_mode() == LSNF_MATH_BF16X3 && m > 0) ? (1 << 28) : m;
 }
 
 int geo_or_fail(LsnfGeo* g, int nz, int width, int depth, int coupling) {
@@ -240,7 +240,7 @@ int lsnf_reverse(const float* plan, int nz, int width, int depth, int coupling, 
     if (B == 0) return LSNF_OK;
     const int vec4 = row_vector_width(g, {z_in, z_out});
     hipError_t e = hipErrorInvalidValue;
-    if (B <= s3_bwd_max() && math_mode() == LSNF_MATH_BF16X3)      // on the bf16 pipe (lsnf_small3_rev.hip)
+    if (B <= s3_rev_max() && math_mode() == LSNF_MATH_BF16X3)      // on the bf16 pipe (lsnf_small3_rev.hip)
         e = lsnf_launch_small3_reverse(g, plan, B, z_in, objective, z_out, objective_out, vec4, (hipStream_t)stream);
     if (e == hipErrorInvalidValue)      // not taken or not covered: the fp32-MFMA kernels of the batch size's family
         e = (B <= small_batch_max())
@@ -265,7 +265,7 @@ int lsnf_backward_z(const float* plan, int nz, int width, int depth, int couplin
     const int vec4 = row_vector_width(g, {z_out, g_z_in, z_saved, g_z1});
     if (act_saved && !aligned16(act_saved)) return fail(LSNF_E_ARG, "lsnf_backward_z: act_saved must be 16-byte aligned");
     hipError_t e = hipErrorInvalidValue;
-    if (B <= s3_bwd_max() && act_saved && math_mode() == LSNF_MATH_BF16X3)     // from the stash, on the bf16 pipe (lsnf_small3_bwd.hip)
+    if (B <= small_batch_max() && act_saved && math_mode() == LSNF_MATH_BF16X3)     // from the stash, on the bf16 pipe (lsnf_small3_bwd.hip)
         e = lsnf_launch_small3_backward_z(g, plan, B, z_out, z_saved, act_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in,
                                           vec4, (hipStream_t)stream, nullptr);
     else if (act_saved && math_mode() == LSNF_MATH_BF16X3 && B > small_batch_max())          // throughput form (lsnf_bwd3.hip)
@@ -303,7 +303,7 @@ int lsnf_langevin_step(const float* plan, int nz, int width, int depth, int coup
                            rng ? LsnfRngArgs{rng->seed, rng->offset, rng->offset_dev, rng->row0, 1}
                                : LsnfRngArgs{0ull, 0ull, nullptr, 0ll, 0}};
     hipError_t e = hipErrorInvalidValue;
-    if (B <= s3_bwd_max() && act_saved && math_mode() == LSNF_MATH_BF16X3)
+    if (B <= small_batch_max() && act_saved && math_mode() == LSNF_MATH_BF16X3)
         e = lsnf_launch_small3_backward_z(g, plan, B, z_out, z_saved, act_saved, nullptr, nullptr, /*ll_mode=*/1,
                                           /*ll_scale=*/-1.0f, nullptr, vec4, (hipStream_t)stream, &lv);
     else if (act_saved && math_mode() == LSNF_MATH_BF16X3 && B > small_batch_max())
