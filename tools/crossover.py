@@ -1,4 +1,7 @@
-"""Latency of the forward (and backward) at several batch sizes on both kernel families -> crossover."""
+"""Latency of the forward / backward (recomputing: bwd, from the stash: bwds) / reverse at several batch sizes on every
+kernel family and arithmetic mode -> the crossovers the ABI's dispatch uses.  Columns: fp32 latency kernels forced,
+throughput kernels forced in bf16x3 and fp32 mode, bf16x3 latency kernels forced (kernels that have no bf16x3 form
+fall back to their fp32 one)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench, lsnf_amd
@@ -29,4 +32,4 @@ for B in (32, 100, 256, 1024, 4096, 8192, 12288, 16384, 20480, 24576, 32768, 491
             z1, ld, ll, sv = lsnf_amd.forward(plan, z, save_for_backward=True, act_saved=act)
             t = timeit(lambda: lsnf_amd.backward_z(plan, z1, sv, ll_scale=-1.0, act_saved=act), 100)
         res.append(t)
-    print(f"{which} B={B:6d}  latency-kernel {res[0]:8.1f} us   throughput-kernel bf16x3 {res[1]:8.1f} us   fp32 MFMA {res[2]:8.1f} us   latency-kernel bf16x3 (16-sample workgroups; above 8192 rows = throughput) {res[3]:8.1f} us")
+    print(f"{which} B={B:6d}  latency-kernel {res[0]:8.1f} us   throughput-kernel bf16x3 {res[1]:8.1f} us   fp32 MFMA {res[2]:8.1f} us   bf16x3 latency family forced (16-sample workgroups) {res[3]:8.1f} us")
