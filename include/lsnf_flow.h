@@ -62,12 +62,11 @@ const char* lsnf_last_error(void);
 /* Tuning knob: batches of at most `rows` rows run on the small-batch (latency) kernels, larger ones on the
  * throughput kernels; both compute the same function (results agree to fp32 rounding, not bit for bit).
  * rows < 0 only queries.  Returns the previous value (default 16384, or the LSNF_SMALL_MAX environment variable).
- * In the LSNF_MATH_BF16X3 mode the reverse uses its (bf16) latency kernel at every batch size unless rows == 0: its
- * throughput counterpart is still fp32 MFMA and no faster anywhere. */
+ */
 int lsnf_set_small_batch_max(int rows);
 
-/* Arithmetic of the GEMMs.  Affects the forward and the backward-from-the-stash (both families) and the latency-family
- * reverse; the parameter gradients, the recomputing backward and the throughput reverse are fp32 MFMA in every mode:
+/* Arithmetic of the GEMMs.  Affects the forward, the backward-from-the-stash and the reverse (both families); the
+ * parameter gradients and the recomputing backward (no stash given) are fp32 MFMA in every mode:
  *   LSNF_MATH_FP32   : fp32 MFMA (v_mfma_f32_32x32x2_f32)
  *   LSNF_MATH_BF16X3 : both operands split error-free into three bf16 terms, six bf16 MFMAs per product with fp32
  *                      accumulation (csrc/lsnf_fwd3.hip, on v_mfma_f32_16x16x32_bf16).  Same accuracy class as fp32

@@ -41,6 +41,8 @@ hipError_t lsnf_launch_backward_z(const LsnfGeo& g, const float* plan, int B, co
                                   const LsnfLangevinArgs* lv = nullptr, const float* act_saved = nullptr);
 hipError_t lsnf_launch_small3_reverse(const LsnfGeo& g, const float* plan, int B, const float* z_in, const float* objective,
                                       float* z_out, float* objective_out, int vec4, hipStream_t stream);
+hipError_t lsnf_launch_reverse3(const LsnfGeo& g, const float* plan, int B, const float* z_in, const float* objective,
+                                float* z_out, float* objective_out, int vec4, hipStream_t stream);
 hipError_t lsnf_launch_small_reverse(const LsnfGeo& g, const float* plan, int B, const float* z_in, const float* objective,
                                      float* z_out, float* objective_out, int vec4, hipStream_t stream);
 hipError_t lsnf_launch_small_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
@@ -100,15 +102,6 @@ int math_mode() {
                : (e && !strcmp(e, "fp32")) ? LSNF_MATH_FP32 : LSNF_MATH_DEFAULT;
     }
     return g_math;
-}
-
-// The bf16x3 latency reverse is at least as fast as the (still fp32-MFMA) throughput reverse at every batch size measured
-// (tools/crossover.py rev: 91 vs 95 us at 32 768 rows, 138 vs 181 at 49 152, 173 vs 185 at 65 536), so in that mode it
-// serves all of them unless the latency kernels are switched off (threshold 0).  The backward has a bf16x3 throughput
-// form (lsnf_bwd3.hip) and crosses over where the forward does.
-int s3_rev_max() {
-    const int m = small_batch_max();
-    return (math_mode() == LSNF_MATH_BF16X3 && m > 0) ? (1 << 28) : m;
 }
 
 int geo_or_fail(LsnfGeo* g, int nz, int width, int depth, int coupling) {
@@ -240,8 +233,13 @@ int lsnf_reverse(const float* plan, int nz, int width, int depth, int coupling, 
     if (B == 0) return LSNF_OK;
     const int vec4 = row_vector_width(g, {z_in, z_out});
     hipError_t e = hipErrorInvalidValue;
-    if (B <= s3_rev_max() && math_mode() == LSNF_MATH_BF16X3)      // on the bf16 pipe (lsnf_small3_rev.hip)
-        e = lsnf_launch_small3_reverse(g, plan, B, z_in, objective, z_out, objective_out, vec4, (hipStream_t)stream);
+    if (math_mode() == LSNF_MATH_BF16X3) {        // on the bf16 pipe: lsnf_small3_rev.hip / lsnf_rev3.hip
+        if (B > small_batch_max())
+            e = lsnf_launch_reverse3(g, plan, B, z_in, objective, z_out, objective_out, vec4, (hipStream_t)stream);
+        // (the latency form is also faster than the fp32 throughput reverse where the bf16 throughput form does not fit)
+        if (e == hipErrorInvalidValue && small_batch_max() > 0)
+            e = lsnf_launch_small3_reverse(g, plan, B, z_in, objective, z_out, objective_out, vec4, (hipStream_t)stream);
+    }
     if (e == hipErrorInvalidValue)      // not taken or not covered: the fp32-MFMA kernels of the batch size's family
         e = (B <= small_batch_max())
             ? lsnf_launch_small_reverse(g, plan, B, z_in, objective, z_out, objective_out, vec4, (hipStream_t)stream)

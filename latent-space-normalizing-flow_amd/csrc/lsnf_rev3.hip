@@ -1,0 +1,163 @@
+// lsnf_rev3.hip -- throughput reverse (sampling) pass on the bf16 matrix pipe: the bf16x3 split and L16 lane layout of
+// lsnf_fwd3.hip's 16x16x32 kernel applied to lsnf_rev.hip (replaces reference model.py:484-498 / :424-456).
+// Per block, last to first, a wave owning 32 samples and all features:
+//   R2,R3,R4 : h = f(z1) -> [t; p]                                (forward panels S2..S4, 16x16x32 operand order)
+//   CI       : z2 = z2 / sigmoid(p) - t ; objective -= sum log sigmoid(p)     (model.py:436-438)
+//   I1       : z = ([z1,z2] @ W^-1) * exp(-3 logs) - b ; objective -= log|det W| + sum 3 logs  (:193-196, 270, 246)
+#include "lsnf_l16.h"
+
+namespace {
+
+template <int HT_, int WT_>
+struct Rev3Cfg : LsnfStackCfg<HT_, WT_> {
+    using S = LsnfStackCfg<HT_, WT_>;
+    static constexpr int F = LSNF_FRAG3_FLOATS;
+    static constexpr int OFF3_S2 = F * S::P1 * S::KT1;
+    static constexpr int OFF3_S3 = OFF3_S2 + F * S::P2 * S::KT2;
+    static constexpr int OFF3_S4 = OFF3_S3 + F * S::P3 * S::KT3;
+    static constexpr int BLOCK3 = OFF3_S4 + F * S::P4 * S::KT4;
+    static constexpr int BLOCKI = F * S::NZT * S::NZT;
+    static constexpr int CONST_PER_BLOCK = S::FWD_CONST + S::INV_CONST;
+    static constexpr int SLOT3 = 2 * S::MAXKT * F;
+};
+
+struct Rev3Args {
+    const float* fwd_consts; const float* inv_consts; const float* panels3b; const float* ipanels3b;
+    const float* z_in; const float* objective; float* z_out; float* objective_out;
+    int B, nz, half, depth, vec4;
+};
+
+template <class C, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void lsnf_rev3_kernel(const Rev3Args a) {
+    constexpr int HT = C::HT, WT = C::WT, NZT = C::NZT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* cst = smem;                                         // depth * CONST_PER_BLOCK
+    float* buf0 = smem + a.depth * C::CONST_PER_BLOCK;         // 2 x SLOT3
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int vec4 = a.vec4;
+
+    const int last = a.depth - 1;
+    Pipe3<NW> pipe;
+    pipe.buf0 = buf0; pipe.slot = C::SLOT3; pipe.wave = wave; pipe.lane = lane;
+    pipe.template prime<first_kib(C::P2, C::KT2)>(a.panels3b + (size_t)last * C::BLOCK3 + C::OFF3_S2);
+    for (int i = tid; i < a.depth * C::CONST_PER_BLOCK; i += 64 * NW) {
+        const int blk = i / C::CONST_PER_BLOCK, r = i % C::CONST_PER_BLOCK;
+        cst[i] = r < C::FWD_CONST ? a.fwd_consts[blk * C::FWD_CONST + r] : a.inv_consts[blk * C::INV_CONST + (r - C::FWD_CONST)];
+    }
+
+    const long base = ((long)blockIdx.x * NW + wave) * 32;
+    long sample[2], rows[2]; bool live[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) { sample[st] = base + 16 * st + n; live[st] = sample[st] < a.B; rows[st] = live[st] ? sample[st] : (long)a.B - 1; }
+
+    f32x16 x[NZT];
+#pragma unroll
+    for (int t = 0; t < NZT; ++t) x[t] = l16_load_tile<HT>(t, a.z_in, rows, a.nz, a.half, g, vec4);
+    float obj[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) obj[st] = a.objective ? a.objective[rows[st]] : 0.0f;
+    auto keep = [](f32x16 acc, int) { return acc; };
+    auto relu = [](f32x16 acc, int) { return lsnf_relu16(acc); };
+
+    for (int blk = last; blk >= 0; --blk) {
+        const float* cb = cst + blk * C::CONST_PER_BLOCK;
+        const float* ci = cb + C::FWD_CONST;
+        const float* gf = a.panels3b + (size_t)blk * C::BLOCK3;
+        const float* gi = a.ipanels3b + (size_t)blk * C::BLOCKI;
+        const float* gnext = blk > 0 ? a.panels3b + (size_t)(blk - 1) * C::BLOCK3 + C::OFF3_S2 : nullptr;
+
+        // ---- R2: h1 = relu(W1'^T z1 + c1) ----
+        f32x16 h1[WT];
+        {
+            Split3 zs[2 * HT];
+            l16_split_tiles<HT>(x, zs);
+            l16_gemm_stage3<C::P2, C::KT2, first_kib(C::P3, C::KT3)>(
+                pipe, gf + C::OFF3_S2, gf + C::OFF3_S3, h1, zs, [&](int t) { return l16_bias_init(cb + 32 * (C::P1 + t), g); }, relu);
+        }
+        // ---- R3 ----
+        f32x16 h2[WT];
+        {
+            Split3 hs[2 * WT];
+            l16_split_tiles<WT>(h1, hs);
+            l16_gemm_stage3<C::P3, C::KT3, first_kib(C::P4, C::KT4)>(
+                pipe, gf + C::OFF3_S3, gf + C::OFF3_S4, h2, hs,
+                [&](int t) { return l16_bias_init(cb + 32 * (C::P1 + C::P2 + t), g); }, relu);
+        }
+        // ---- R4: [t; p] ----
+        f32x16 tp[2 * HT];
+        {
+            Split3 hs[2 * WT];
+            l16_split_tiles<WT>(h2, hs);
+            l16_gemm_stage3<C::P4, C::KT4, first_kib(NZT, NZT)>(
+                pipe, gf + C::OFF3_S4, gi, tp, hs,
+                [&](int t) { return l16_bias_init(cb + 32 * (C::P1 + C::P2 + C::P3 + t), g); }, keep);
+        }
+        // ---- inverse coupling (model.py:436-438) ----
+        float lsum[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sig, lsig;
+                lsnf_sigmoid_logsig(tp[HT + t][r], sig, lsig);
+                x[HT + t][r] = x[HT + t][r] / sig - tp[t][r];
+                lsum[(r >> 2) & 1] += lsig;
+            }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            obj[st] = obj[st] - l16_group_sum(lsum[st]);
+            obj[st] = obj[st] - cb[32 * C::NP + 1];   // logdet - log|det W|       (model.py:196)
+            obj[st] = obj[st] - cb[32 * C::NP + 0];   // logdet - sum(3 logs)      (model.py:273-276, reverse)
+        }
+        // ---- I1: z = Winv'^T [z1; z2] + cinv ----
+        {
+            Split3 us[2 * NZT];
+            l16_split_tiles<NZT>(x, us);
+            f32x16 xn[NZT];
+            l16_gemm_stage3<NZT, NZT, first_kib(C::P2, C::KT2)>(
+                pipe, gi, gnext, xn, us, [&](int t) { return l16_bias_init(ci + 32 * t, g); }, keep);
+#pragma unroll
+            for (int t = 0; t < NZT; ++t) x[t] = xn[t];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NZT; ++t) l16_store_tile<HT>(t, x[t], a.z_out, sample, live, a.nz, a.half, g, vec4);
+    if (a.objective_out) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+            if (live[st] && g == 0) a.objective_out[sample[st]] = obj[st];
+    }
+}
+
+template <class C, int NW>
+hipError_t launch_rev3_w(const Rev3Args& a, hipStream_t stream) {
+    const size_t lds = ((size_t)a.depth * C::CONST_PER_BLOCK + 2 * (size_t)C::SLOT3) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto kern = lsnf_rev3_kernel<C, NW>;
+    static unsigned long long lds_ok = 0;
+    if (hipError_t e = lsnf_allow_big_lds((const void*)kern, &lds_ok); e != hipSuccess) return e;
+    const unsigned grid = (unsigned)((a.B + 32 * NW - 1) / (32 * NW));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, a);
+    return hipGetLastError();
+}
+template <class C>
+hipError_t launch_rev3(const Rev3Args& a, hipStream_t stream) {
+    return a.B > 128 * 256 ? launch_rev3_w<C, 8>(a, stream) : launch_rev3_w<C, 4>(a, stream);
+}
+}  // namespace
+
+// host-side dispatcher (called from lsnf_api.hip); hipErrorInvalidValue = not covered (e.g. very deep stacks: LDS)
+hipError_t lsnf_launch_reverse3(const LsnfGeo& g, const float* plan, int B, const float* z_in, const float* objective,
+                                float* z_out, float* objective_out, int vec4, hipStream_t stream) {
+    Rev3Args a;
+    a.fwd_consts = plan + g.off_fwd_const; a.inv_consts = plan + g.off_inv_const;
+    a.panels3b = plan + g.off_f3b_panels; a.ipanels3b = plan + g.off_i3b_panels;
+    a.z_in = z_in; a.objective = objective; a.z_out = z_out; a.objective_out = objective_out;
+    a.B = B; a.nz = g.nz; a.half = g.half; a.depth = g.depth; a.vec4 = vec4;
+    if (g.HT == 1 && g.WT == 1) return launch_rev3<Rev3Cfg<1, 1>>(a, stream);
+    if (g.HT == 2 && g.WT == 2) return launch_rev3<Rev3Cfg<2, 2>>(a, stream);
+    if (g.HT == 2 && g.WT == 4) return launch_rev3<Rev3Cfg<2, 4>>(a, stream);
+    return hipErrorInvalidValue;
+}
