@@ -105,7 +105,8 @@ def main():
         loss_g.backward()
         optG.step()
         optF.zero_grad(set_to_none=True)                        # train.py:404-415, fused: loss and the 60 gradients in 5 launches,
-        loss_f = netF.mle_grads(zk.view(B, nz), max_norm=100.0 if world == 1 else None)   # then the one-bucket all-reduce
+        loss_f = netF.mle_grads(zk.view(B, nz), max_norm=100.0 if world == 1 else None,   # then the one-bucket all-reduce
+                                reuse_buffers=True)
         if world > 1:
             parallel.allreduce_gradients(netF.parameters(), average=True)
             torch.nn.utils.clip_grad_norm_(netF.parameters(), 100.0)

@@ -295,10 +295,13 @@ def langevin_step(plan: FlowPlan, z: torch.Tensor, grad_g: Optional[torch.Tensor
 def backward_params(plan: FlowPlan, params: Sequence[torch.Tensor], z_in: torch.Tensor, z_out: torch.Tensor,
                     z_saved: Optional[torch.Tensor], g_z1: Optional[torch.Tensor] = None,
                     g_logdet: Optional[torch.Tensor] = None, ll_scale: Optional[float] = None,
-                    want_grad_z: bool = False, want_flat: bool = False):
+                    want_grad_z: bool = False, want_flat: bool = False, reuse_buffers: bool = False):
     """dL/dtheta for the depth*12 live tensors (train.py:406-411).  Returns a list of gradients shaped like
     `params` (and dL/dz_in as a second value if want_grad_z; and, last, the ONE flat buffer the gradients are views
-    of if want_flat -- a global norm / clip is then one reduction instead of 60)."""
+    of if want_flat -- a global norm / clip is then one reduction instead of 60).  reuse_buffers: keep the flat
+    gradient buffer, its 60 views, the pointer tables and the workspace on the plan between calls (as long as the
+    parameter storages and B do not change) -- the returned gradient tensors are then THE SAME objects every call,
+    overwritten in place (an optimizer that consumes .grad before the next call does not notice; ~0.2 ms of host time)."""
     lib = _lib.load()
     _need_cuda(z_in, "z_in")
     _need_cuda(z_out, "z_out")
@@ -308,28 +311,28 @@ def backward_params(plan: FlowPlan, params: Sequence[torch.Tensor], z_in: torch.
     for name, t in (("z_saved", z_saved), ("g_z1", g_z1), ("g_logdet", g_logdet)):
         if t is not None:
             _need_cuda(t, name)
-    # one flat gradient buffer, handed out as views (60 separate allocations cost ~200 us of host time)
-    raw = [p.detach() for p in params]
-    sizes = [t.numel() for t in raw]
-    flat = torch.empty(sum(sizes), dtype=torch.float32, device=z_out.device)
-    grads = [g.view(t.shape) for g, t in zip(flat.split(sizes), raw)]
-    g_in = torch.empty_like(z_out) if want_grad_z else None
-    nws = lib.lsnf_backward_params_workspace_floats(plan.nz, plan.width, plan.depth, B)
-    ws = torch.empty(nws, dtype=torch.float32, device=z_out.device)
-    ptrs = tuple(t.data_ptr() for t in raw)
-    cache = plan.__dict__.setdefault("_ptr_cache", {})
-    parr = cache.get(ptrs)
-    if parr is None:                      # validated once per distinct set of parameter storages
+    key = (tuple(p.data_ptr() for p in params), B, z_out.device, want_grad_z)
+    st = plan.__dict__.get("_bp_state") if reuse_buffers else None
+    if st is None or st["key"] != key:
+        # one flat gradient buffer, handed out as views (60 separate allocations cost ~200 us of host time)
+        raw = [p.detach() for p in params]
         for i, t in enumerate(raw):
             _need_cuda(t, f"param[{i}]")
-        cache.clear()
-        parr = cache[ptrs] = (ctypes.c_void_p * len(raw))(*ptrs)
-    base, esz = flat.data_ptr(), 4
-    offs, o = [], 0
-    for n in sizes:
-        offs.append(base + o * esz)
-        o += n
-    garr = (ctypes.c_void_p * len(grads))(*offs)
+        sizes = [t.numel() for t in raw]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=z_out.device)
+        grads = [g.view(t.shape) for g, t in zip(flat.split(sizes), raw)]
+        nws = lib.lsnf_backward_params_workspace_floats(plan.nz, plan.width, plan.depth, B)
+        base, o, offs = flat.data_ptr(), 0, []
+        for n in sizes:
+            offs.append(base + o * 4)
+            o += n
+        st = {"key": key, "flat": flat, "grads": grads,
+              "g_in": torch.empty_like(z_out) if want_grad_z else None,
+              "ws": torch.empty(nws, dtype=torch.float32, device=z_out.device),
+              "parr": (ctypes.c_void_p * len(raw))(*key[0]), "garr": (ctypes.c_void_p * len(raw))(*offs)}
+        if reuse_buffers:
+            plan.__dict__["_bp_state"] = st
+    flat, grads, g_in, ws, parr, garr = st["flat"], st["grads"], st["g_in"], st["ws"], st["parr"], st["garr"]
     with torch.cuda.device(z_out.device):
         rc = lib.lsnf_backward_params(_ptr(plan.buf), parr, garr, plan.nz, plan.width, plan.depth, plan.coupling, B,
                                       _ptr(z_in), _ptr(z_out), _ptr(z_saved), _ptr(g_z1), _ptr(g_logdet),

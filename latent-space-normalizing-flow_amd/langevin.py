@@ -51,7 +51,8 @@ def flow_mle_step(netF, optF, z_g_k, f_max_norm: Optional[float] = None, fused: 
     import numpy as np
     if fused:
         optF.zero_grad(set_to_none=True)
-        loss_f = netF.mle_grads(z_g_k.reshape(z_g_k.shape[0], -1), max_norm=f_max_norm)   # clip: train.py:413-414
+        loss_f = netF.mle_grads(z_g_k.reshape(z_g_k.shape[0], -1), max_norm=f_max_norm,    # clip: train.py:413-414
+                                reuse_buffers=True)
         optF.step()
         return loss_f
     optF.zero_grad()

@@ -273,12 +273,14 @@ class _netF(nn.Module):
                                   None if grad_g is None else grad_g.detach().contiguous(), noise, step_size,
                                   inplace=inplace, reuse_buffers=reuse_buffers)
 
-    def mle_grads(self, z, accumulate: bool = False, max_norm: Optional[float] = None):
+    def mle_grads(self, z, accumulate: bool = False, max_norm: Optional[float] = None, reuse_buffers: bool = False):
         """Fused flow-MLE gradients (train.py:404-411): loss_f = -mean_b ll(z_b) and d loss_f / d theta written to
         `.grad` of the 60 live tensors -- forward (ll summed in-kernel), dump backward, batch contraction, unfold:
         5 launches and no autograd graph.  max_norm: clip the global gradient norm (train.py:413-414
         `clip_grad_norm_`) on the one flat buffer the gradients are views of (3 launches instead of a foreach over
-        60 tensors; only without `accumulate`).  Returns loss_f as a 0-dim device tensor (no host sync)."""
+        60 tensors; only without `accumulate`).  reuse_buffers: the gradient tensors are the same objects every call,
+        overwritten in place (`flow.backward_params`): for loops that consume `.grad` before the next call.
+        Returns loss_f as a 0-dim device tensor (no host sync)."""
         plan = self._plan()
         z = z.detach().contiguous()
         B = z.shape[0]
@@ -287,13 +289,14 @@ class _netF(nn.Module):
         stats = flow.new_stats(z.device)
         z1, _, _, saved = flow.forward(plan, z, None, want_ll=False, save_for_backward=True, stats=stats)
         params = self._param_list()
-        grads, flat = flow.backward_params(plan, params, z, z1, saved, ll_scale=-1.0 / B, want_flat=True)
+        grads, flat = flow.backward_params(plan, params, z, z1, saved, ll_scale=-1.0 / B, want_flat=True,
+                                           reuse_buffers=reuse_buffers and not accumulate)
         if max_norm is not None:
             if accumulate:
                 raise LsnfError("max_norm clips the gradients of this call only: not with accumulate=True")
             flat.mul_(torch.clamp(float(max_norm) / (flat.norm() + 1e-6), max=1.0))   # torch's clip_grad_norm_ formula
         for p, g in zip(params, grads):
-            if not p.requires_grad:
+            if not p.requires_grad or p.grad is g:
                 continue
             p.grad = g if (p.grad is None or not accumulate) else p.grad + g
         return (stats[4] * (-1.0 / B)).to(torch.float32)

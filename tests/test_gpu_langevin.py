@@ -144,6 +144,19 @@ def test_sampler_and_mle_step_harness_vs_oracle(lsnf, gpu_device):
     net.mle_grads(z2d, max_norm=10.0 * total)          # above the norm: untouched
     for k in ref:
         assert (net.get_parameter(k).grad - ref[k]).norm().item() <= 1e-5 * max(ref[k].norm().item(), 1e-3), k
+    # reuse_buffers: the same gradient tensors every call, same values; a changed batch size re-allocates
+    net.zero_grad(set_to_none=True)
+    net.mle_grads(z2d, reuse_buffers=True)
+    first = {k: v.grad for k, v in net.named_parameters() if v.grad is not None}
+    for k in ref:
+        first[k].add_(1.0)                                  # stale contents must be overwritten, not accumulated
+    net.mle_grads(z2d, reuse_buffers=True)
+    for k in ref:
+        assert net.get_parameter(k).grad is first[k], k
+        assert (first[k] - ref[k]).norm().item() <= 1e-5 * max(ref[k].norm().item(), 1e-3), k
+    net.mle_grads(z2d[: B // 2], reuse_buffers=True)
+    assert all(net.get_parameter(k).grad is not first[k] for k in ref)
+    assert all(torch.isfinite(net.get_parameter(k).grad).all() for k in ref)
     l2 = lsnf.langevin.flow_mle_step(net, opt, zk, f_max_norm=100.0, fused=True)
     l3 = lsnf.langevin.flow_mle_step(net, opt, zk, f_max_norm=100.0, fused=True)
     assert l3.item() < l2.item() <= l1.item()

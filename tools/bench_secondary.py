@@ -66,6 +66,9 @@ for (tag, nz, w, B) in [("C2/C4 SVHN/CelebA nz=100 w=64 B=100", 100, 64, 100), (
         net.zero_grad(set_to_none=True)
         net.mle_grads(z)
     r["mle_fused_grads_us"] = timeit(mle_fused, max(10, n // 4), 5)
+    def mle_fused_reuse():
+        net.mle_grads(z, reuse_buffers=True)
+    r["mle_fused_grads_reused_buffers_us"] = timeit(mle_fused_reuse, max(10, n // 4), 5)
     params = [p.detach() for p in net._param_list()]
     r["prepare_us"] = timeit(lambda: lsnf_amd.prepare(params, nz, w, 5, plan=plan), 20, 3)
     flop = 5 * (2 * nz * nz + 2 * (nz // 2 * w + w * w + w * nz)) * B
