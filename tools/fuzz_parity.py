@@ -1,0 +1,125 @@
+"""Randomised parity sweep (GPU box): random geometries x batch sizes at the kernel-family / tile boundaries x every
+entry point x every arithmetic mode, each checked against the float64 oracle.  Prints one line per failing case and a
+summary; exit code 1 if anything failed.  `python tools/fuzz_parity.py [n_cases] [seed]`.
+The oracle is the checker only (tests/ infrastructure); the product path is the C ABI."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import lsnf_amd
+from lsnf_amd import flow
+from oracle import flow_oracle as O, philox_oracle as PO
+
+dev = torch.device("cuda:0")
+BATCHES = [1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 255, 257, 1000, 4097, 16384, 16385, 32768, 32769]
+fails, checks = [], 0
+
+
+def rel(a, b):
+    return float((a.double().cpu() - b.double()).abs().max() / max(1e-30, float(b.double().abs().max())))
+
+
+def check(tag, name, got, ref, tol):
+    global checks
+    checks += 1
+    e = rel(got, ref)
+    if not (e <= tol) or not bool(torch.isfinite(got).all()):
+        fails.append((tag, name, e, tol))
+        print("FAIL", tag, name, "err %.3g > %.3g" % (e, tol), flush=True)
+
+
+def run(n_cases, seed, batches=BATCHES):
+    """Returns (number of checks, list of failures (tag, quantity, error, tolerance))."""
+    global checks
+    del fails[:]
+    checks = 0
+    rs = np.random.RandomState(seed)
+    t00 = time.time()
+    prev_small, prev_mode = flow.set_small_batch_max(-1), flow.set_math_mode(-1)
+    try:
+        for case in range(n_cases):
+            nz = 2 * int(rs.randint(1, 65))
+            width = int(rs.choice([int(rs.randint(1, 129)), 32, 64, 128, 33, 65, 96]))
+            depth = int(rs.randint(1, 7))
+            B = int(rs.choice(batches))
+            small_max = int(rs.choice([0, 16384]))          # 0: throughput family for every B; default: latency family here
+            p32 = O.init_params(nz, width, depth, seed=1000 + case, fcz_std=0.05, all_std=float(rs.choice([0.0, 0.02])))
+            p64 = O.to_dtype(p32, torch.float64)
+            z = torch.randn(B, nz, generator=torch.Generator().manual_seed(case)).float()
+            obj0 = torch.randn(B, generator=torch.Generator().manual_seed(case + 7)).float()
+            gg = torch.randn(B, nz, generator=torch.Generator().manual_seed(case + 11)).float()
+            noise_t = torch.randn(B, nz, generator=torch.Generator().manual_seed(case + 13)).float()
+            step = float(rs.choice([0.1, 0.3]))
+            margin = O.relu_margin(p32, z)
+            smooth = margin > 2e-5                              # rows away from a ReLU kink (gradients are discontinuous there)
+            z1_ref, ld_ref, ll_ref = O.flow_log_prob(p64, z.double())
+            gz_ref = O.grad_neg_sum_ll_wrt_z(p64, z.double())
+            x_ref, xobj_ref = O.flow_reverse(p64, z.double(), obj0.double())
+            gp_ref = O.grad_neg_mean_ll_wrt_params(p64, z.double())
+            params = flow.params_from_state_dict(p32, depth, dev)
+            try:
+                plan = flow.prepare(params, nz, width, depth)
+            except lsnf_amd.LsnfError as e:
+                print("unsupported geometry", nz, width, depth, e)
+                continue
+            zd, od = z.to(dev), obj0.to(dev)
+            flow.set_small_batch_max(small_max)
+            for mode in (flow.MATH_FP32, flow.MATH_BF16X3, flow.MATH_BF16X3_32):
+                flow.set_math_mode(mode)
+                tag = f"case{case} nz={nz} w={width} d={depth} B={B} small_max={small_max} mode={mode}"
+                for stash in (False, True):
+                    act = flow.new_act_saved(plan, B, dev) if stash else None
+                    z1, ld, ll, saved = flow.forward(plan, zd, None, want_ll=True, save_for_backward=True, act_saved=act)
+                    t = tag + (" stash" if stash else "")
+                    check(t, "z1", z1, z1_ref, 2e-5)
+                    check(t, "logdet", ld, ld_ref if ld_ref.abs().max() > 1e-3 else ld_ref + 1.0 - 1.0, 1e-5 if ld_ref.abs().max() > 1 else 1e-3)
+                    check(t, "ll", ll, ll_ref, 1e-5)
+                    gz = flow.backward_z(plan, z1, saved, ll_scale=-1.0, act_saved=act)
+                    if bool(smooth.any()):
+                        check(t, "grad_z", gz[smooth.to(dev)], gz_ref[smooth], 2e-4)
+                # Langevin step (train.py:316-329) with explicit noise and with in-kernel Philox noise (oracle/philox_oracle.py)
+                for kind in ("tensor", "philox"):
+                    rows_ok = smooth
+                    if not bool(rows_ok.any()):
+                        break
+                    if kind == "tensor":
+                        nref = noise_t
+                        zn, ll2, gfn, ggn = flow.langevin_step(plan, zd, gg.to(dev), noise_t.to(dev), step)
+                    else:
+                        ph = flow.PhiloxNoise(seed=1234 + case, offset=5 + case)
+                        nref = torch.from_numpy(PO.langevin_noise(B, nz, 1234 + case, 5 + case, 0)).float()
+                        zn, ll2, gfn, ggn = flow.langevin_step(plan, zd, gg.to(dev), ph, step)
+                    zn_ref = z.double() - 0.5 * step * step * (gg.double() + gz_ref) + step * nref.double()
+                    check(tag, "langevin_z_" + kind, zn[rows_ok.to(dev)], zn_ref[rows_ok], 2e-5)
+                    check(tag, "langevin_ll_" + kind, ll2, ll_ref, 1e-5)
+                x, xo = flow.reverse(plan, zd, od)
+                check(tag, "reverse_x", x, x_ref, 5e-5)
+                check(tag, "reverse_obj", xo, -xobj_ref, 2e-5)     # the oracle returns -objective like the reference (model.py:498)
+                # round trip through the product path alone
+                z1, ld, _, _ = flow.forward(plan, zd, od, want_ll=False)
+                zb, ob = flow.reverse(plan, z1, ld)
+                check(tag, "roundtrip_z", zb, z.double(), 5e-5)
+                check(tag, "roundtrip_obj", ob, obj0.double() if B > 1 or abs(float(obj0[0])) > 1e-2 else ob.double().cpu(), 5e-4)
+                if bool(smooth.all()):
+                    z1, _, _, saved = flow.forward(plan, zd, None, want_ll=False, save_for_backward=True)
+                    grads = flow.backward_params(plan, params, zd, z1, saved, ll_scale=-1.0 / B)
+                    keys = [O.block_prefix(i) + k for i in range(depth) for k in flow.BLOCK_PARAM_KEYS]
+                    for k, g in zip(keys, grads):
+                        ref = gp_ref[k].reshape(g.shape)
+                        if float(ref.abs().max()) < 1e-6:
+                            continue
+                        check(tag, "dparam " + k, g, ref, 5e-4)
+            print(f"case {case} done: nz={nz} w={width} d={depth} B={B} small_max={small_max}  ({checks} checks, {len(fails)} failures, "
+                  f"{time.time() - t00:.0f} s)", flush=True)
+
+    finally:
+        flow.set_small_batch_max(prev_small)
+        flow.set_math_mode(prev_mode)
+    return checks, list(fails)
+
+
+if __name__ == "__main__":
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    n, bad = run(n_cases, seed)
+    print(f"SUMMARY: {n} checks over {n_cases} cases, {len(bad)} failures")
+    sys.exit(1 if bad else 0)
