@@ -24,7 +24,11 @@ hipError_t lsnf_launch_forward(const LsnfGeo& g, const float* plan, int first_bl
 hipError_t lsnf_launch_forward3(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                 const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                 float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
-                                int shape16, hipStream_t stream);
+                                int shape16, unsigned* guard, hipStream_t stream);
+hipError_t lsnf_launch_forward2h(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
+                                 const float* z_in, const float* objective, float* z_out, float* logdet_out,
+                                 float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
+                                 int shape16, unsigned* guard, hipStream_t stream);
 hipError_t lsnf_launch_small3_forward(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                       const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                       float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
@@ -99,10 +103,12 @@ int math_mode() {
     if (g_math < 0) {
         const char* e = getenv("LSNF_MATH");
         g_math = (e && !strcmp(e, "bf16x3")) ? LSNF_MATH_BF16X3 : (e && !strcmp(e, "bf16x3_32")) ? LSNF_MATH_BF16X3_32
-               : (e && !strcmp(e, "fp32")) ? LSNF_MATH_FP32 : LSNF_MATH_DEFAULT;
+               : (e && !strcmp(e, "fp16x2")) ? LSNF_MATH_FP16X2 : (e && !strcmp(e, "fp32")) ? LSNF_MATH_FP32 : LSNF_MATH_DEFAULT;
     }
     return g_math;
 }
+// modes whose latency / backward / reverse kernels are the bf16x3 "L16" ones (LSNF_MATH_FP16X2 changes the throughput forward only)
+bool l16_math() { return math_mode() == LSNF_MATH_BF16X3 || math_mode() == LSNF_MATH_FP16X2; }
 
 int geo_or_fail(LsnfGeo* g, int nz, int width, int depth, int coupling) {
     if (lsnf_geo_init(g, nz, width, depth, coupling))
@@ -124,7 +130,7 @@ int lsnf_set_small_batch_max(int rows) {
 }
 int lsnf_set_math_mode(int mode) {
     const int prev = math_mode();
-    if (mode == LSNF_MATH_FP32 || mode == LSNF_MATH_BF16X3 || mode == LSNF_MATH_BF16X3_32) g_math = mode;
+    if (mode == LSNF_MATH_FP32 || mode == LSNF_MATH_BF16X3 || mode == LSNF_MATH_BF16X3_32 || mode == LSNF_MATH_FP16X2) g_math = mode;
     return prev;
 }
 const char* lsnf_last_error(void) { return g_err; }
@@ -195,7 +201,7 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
     const int fwd_small_max = small_batch_max();
     if (B <= fwd_small_max) {
         e = hipErrorInvalidValue;
-        if (math_mode() == LSNF_MATH_BF16X3)      // latency forward on the bf16 pipe: 16-sample workgroups (lsnf_small3_fwd.hip)
+        if (l16_math())                           // latency forward on the bf16 pipe: 16-sample workgroups (lsnf_small3_fwd.hip)
             e = lsnf_launch_small3_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
                                            z_saved, act_saved, stats, vec4, (hipStream_t)stream);
         if (e == hipErrorInvalidValue)
@@ -203,9 +209,20 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
                                           z_saved, act_saved, stats, vec4, (hipStream_t)stream);
     } else {
         e = hipErrorInvalidValue;
-        if (split)                                // error-free split on the bf16 matrix pipe (lsnf_fwd3.hip)
+        // (the fix-up pass re-reads the inputs: not for in-place calls)
+        const bool fp16_ok = math_mode() == LSNF_MATH_FP16X2 && z_in != z_out && (objective == nullptr || objective != logdet_out);
+        if (fp16_ok) {                            // two fp16 terms per operand, three MFMAs per product (lsnf_fwd2h.hip) ...
+            unsigned* guard = reinterpret_cast<unsigned*>(const_cast<float*>(plan) + g.off_guard);
+            e = lsnf_launch_forward2h(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
+                                      z_saved, act_saved, stats, vec4, 1, guard, (hipStream_t)stream);
+            if (e == hipSuccess)                  // ... and the bf16x3 fix-up pass behind it: exits at once unless the fp16
+                                                  // kernel met an operand outside fp16's range, else recomputes every row
+                e = lsnf_launch_forward3(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
+                                         z_saved, act_saved, stats, vec4, 1, guard, (hipStream_t)stream);
+        }
+        if (split || (e == hipErrorInvalidValue && math_mode() == LSNF_MATH_FP16X2))   // error-free split on the bf16 matrix pipe (lsnf_fwd3.hip)
             e = lsnf_launch_forward3(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
-                                     z_saved, act_saved, stats, vec4, math_mode() == LSNF_MATH_BF16X3, (hipStream_t)stream);
+                                     z_saved, act_saved, stats, vec4, math_mode() != LSNF_MATH_BF16X3_32, nullptr, (hipStream_t)stream);
         if (e == hipErrorInvalidValue)            // fp32 MFMA kernel (also: stacks too deep for fwd3's LDS budget)
             e = lsnf_launch_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
                                     z_saved, act_saved, stats, vec4, (hipStream_t)stream);
@@ -233,7 +250,7 @@ int lsnf_reverse(const float* plan, int nz, int width, int depth, int coupling, 
     if (B == 0) return LSNF_OK;
     const int vec4 = row_vector_width(g, {z_in, z_out});
     hipError_t e = hipErrorInvalidValue;
-    if (math_mode() == LSNF_MATH_BF16X3) {        // on the bf16 pipe: lsnf_small3_rev.hip / lsnf_rev3.hip
+    if (l16_math()) {        // on the bf16 pipe: lsnf_small3_rev.hip / lsnf_rev3.hip
         if (B > small_batch_max())
             e = lsnf_launch_reverse3(g, plan, B, z_in, objective, z_out, objective_out, vec4, (hipStream_t)stream);
         // (the latency form is also faster than the fp32 throughput reverse where the bf16 throughput form does not fit)
@@ -263,10 +280,10 @@ int lsnf_backward_z(const float* plan, int nz, int width, int depth, int couplin
     const int vec4 = row_vector_width(g, {z_out, g_z_in, z_saved, g_z1});
     if (act_saved && !aligned16(act_saved)) return fail(LSNF_E_ARG, "lsnf_backward_z: act_saved must be 16-byte aligned");
     hipError_t e = hipErrorInvalidValue;
-    if (B <= small_batch_max() && act_saved && math_mode() == LSNF_MATH_BF16X3)     // from the stash, on the bf16 pipe (lsnf_small3_bwd.hip)
+    if (B <= small_batch_max() && act_saved && l16_math())     // from the stash, on the bf16 pipe (lsnf_small3_bwd.hip)
         e = lsnf_launch_small3_backward_z(g, plan, B, z_out, z_saved, act_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in,
                                           vec4, (hipStream_t)stream, nullptr);
-    else if (act_saved && math_mode() == LSNF_MATH_BF16X3 && B > small_batch_max())          // throughput form (lsnf_bwd3.hip)
+    else if (act_saved && l16_math() && B > small_batch_max())          // throughput form (lsnf_bwd3.hip)
         e = lsnf_launch_backward3_z(g, plan, B, z_out, z_saved, act_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, vec4,
                                     (hipStream_t)stream, nullptr);
     if (e == hipErrorInvalidValue)      // not taken or not covered: the fp32-MFMA kernels of the batch size's family
@@ -301,10 +318,10 @@ int lsnf_langevin_step(const float* plan, int nz, int width, int depth, int coup
                            rng ? LsnfRngArgs{rng->seed, rng->offset, rng->offset_dev, rng->row0, 1}
                                : LsnfRngArgs{0ull, 0ull, nullptr, 0ll, 0}};
     hipError_t e = hipErrorInvalidValue;
-    if (B <= small_batch_max() && act_saved && math_mode() == LSNF_MATH_BF16X3)
+    if (B <= small_batch_max() && act_saved && l16_math())
         e = lsnf_launch_small3_backward_z(g, plan, B, z_out, z_saved, act_saved, nullptr, nullptr, /*ll_mode=*/1,
                                           /*ll_scale=*/-1.0f, nullptr, vec4, (hipStream_t)stream, &lv);
-    else if (act_saved && math_mode() == LSNF_MATH_BF16X3 && B > small_batch_max())
+    else if (act_saved && l16_math() && B > small_batch_max())
         e = lsnf_launch_backward3_z(g, plan, B, z_out, z_saved, act_saved, nullptr, nullptr, /*ll_mode=*/1, /*ll_scale=*/-1.0f,
                                     nullptr, vec4, (hipStream_t)stream, &lv);
     if (e == hipErrorInvalidValue)      // not taken or not covered: the fp32-MFMA kernels of the batch size's family

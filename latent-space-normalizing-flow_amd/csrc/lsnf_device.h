@@ -68,7 +68,9 @@ __device__ __forceinline__ void lsnf_publish_stats(double* stats, double sum_ll,
         const double fl = atomicAdd(&stats[0], 0.0);
         const double fd = atomicAdd(&stats[1], 0.0);
         stats[4] = fl; stats[5] = fd; stats[6] = (double)rows;
-        atomicAdd(&stats[0], -fl); atomicAdd(&stats[1], -fd);      // fire and forget
+        // re-arm, fire and forget (a non-finite sum cannot be subtracted away: NaN - NaN stays NaN for every later launch)
+        if (fl - fl == 0.0) atomicAdd(&stats[0], -fl); else atomicExch(reinterpret_cast<unsigned long long*>(&stats[0]), 0ull);
+        if (fd - fd == 0.0) atomicAdd(&stats[1], -fd); else atomicExch(reinterpret_cast<unsigned long long*>(&stats[1]), 0ull);
         atomicExch(ticket, 0ull);
     }
 }

@@ -27,7 +27,7 @@ namespace {
 template <int HT_, int WT_>
 struct Fwd3Cfg : LsnfStackCfg<HT_, WT_> {
     using S = LsnfStackCfg<HT_, WT_>;
-    static constexpr int F = LSNF_FRAG3_FLOATS;
+    static constexpr int F = L16_FRAG_FLOATS;
     static constexpr int OFF3_S2 = F * S::P1 * S::KT1;
     static constexpr int OFF3_S3 = OFF3_S2 + F * S::P2 * S::KT2;
     static constexpr int OFF3_S4 = OFF3_S3 + F * S::P3 * S::KT3;
@@ -44,6 +44,8 @@ struct Fwd3Args {
     double* stats;
     unsigned long long* stamps;        // LSNF_STAMPS diagnostic build only: [waves & 2047][64] clock stamps
     int shape16;                       // 1: the v_mfma_f32_16x16x32_bf16 variant (panels3 then points at its operand order)
+    unsigned* guard;                   // fp16 range guard (lsnf_layout.h off_guard) or nullptr.  fp16x2 kernel: raises [1];
+                                       // bf16x3 L16 kernel: runs only if [1] is raised (the fix-up pass), then lowers it
 };
 
 #ifdef LSNF_STAMPS   // in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz (tools/stamps_fwd3.py)
@@ -55,6 +57,8 @@ struct Fwd3Args {
 #else
 #define F3_STAMP(i, INSN) do {} while (0)
 #endif
+
+#if LSNF_L16_PARTS == 3   // the 32x32x16 variant exists for the bf16x3 split only
 
 // registers 8*s .. 8*s+7 of an activation tile -> x1, x2, x3 of k-step s
 __device__ __forceinline__ void split_kstep(const f32x16& x, int s, Split3& out) {
@@ -319,6 +323,8 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3_kernel(const Fwd3A
     F3_STAMP(51, "s_memrealtime");
 }
 
+#endif  // LSNF_L16_PARTS == 3
+
 // =====================================================================================================================
 // The same kernel on v_mfma_f32_16x16x32_bf16 ("L16" lane layout of lsnf_layout.h: a wave's 32 samples are two sample
 // tiles st of 16; lane = (n = lane & 15, g = lane >> 4); register (2*ft + st)*4 + r of a 32-feature activation tile
@@ -339,6 +345,18 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3b_kernel(const Fwd3
 
     F3_STAMP(0, "s_memtime");
     F3_STAMP(50, "s_memrealtime");
+#if LSNF_L16_PARTS == 3
+    if (a.guard && a.guard[1] == 0u) return;      // fix-up pass of the fp16 forward: nothing overflowed (kernel-uniform)
+#else
+    if (a.guard[0] != 0u) {                       // weights outside fp16's range (prepare): leave everything to the fix-up pass
+        if (tid == 0) a.guard[1] = 1u;
+        return;
+    }
+    // Range guard.  An operand x with |x| >= 65520 splits into x1 = +-inf, x2 = x - x1 = -+inf, and every output of the
+    // GEMM that consumes it becomes NaN (w*inf - w*inf, or 0*inf where w = 0): looking at ONE output register per
+    // sample tile after each stage sees it -- before the ReLU, which would swallow the NaN (v_max_f32(NaN, 0) = 0).
+    bool bad = false;
+#endif
     Pipe3<F3_WAVES> pipe;
     pipe.buf0 = buf0; pipe.slot = C::SLOT3; pipe.wave = wave; pipe.lane = lane;
     pipe.template prime<first_kib(C::P1, C::KT1)>(a.panels3);
@@ -365,8 +383,13 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3b_kernel(const Fwd3
         const float* gblk = a.panels3 + (size_t)blk * C::BLOCK3;
         const bool more = blk + 1 < a.n_blocks;
         const float* gnext = more ? gblk + C::BLOCK3 : nullptr;
+#if LSNF_L16_PARTS == 3
         auto keep = [](f32x16 acc, int) { return acc; };
         auto relu = [](f32x16 acc, int) { return lsnf_relu16(acc); };
+#else
+        auto keep = [&](f32x16 acc, int t) { if (t == 0) bad = bad || acc[0] != acc[0] || acc[4] != acc[4]; return acc; };
+        auto relu = [&](f32x16 acc, int t) { if (t == 0) bad = bad || acc[0] != acc[0] || acc[4] != acc[4]; return lsnf_relu16(acc); };
+#endif
 
         // ---- S1: v = Wa^T x + ca  (model.py:244,268,187) ----
         f32x16 v[NZT];
@@ -476,6 +499,16 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3b_kernel(const Fwd3
             lsnf_publish_stats(a.stats, tl, td, a.B);
         }
     }
+#if LSNF_L16_PARTS == 3
+    if (a.guard) {                                // fix-up pass done: the workgroup drawing the last ticket lowers the flag
+        __syncthreads();
+        if (tid == 0 && atomicAdd(&a.guard[2], 1u) == gridDim.x - 1) { atomicExch(&a.guard[1], 0u); atomicExch(&a.guard[2], 0u); }
+    }
+#else
+    // an operand at or beyond fp16's range (NaN compares false: it propagates by itself): results of this launch are
+    // not to be trusted -- raise the flag, the bf16x3 fix-up pass queued behind this kernel recomputes every row
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) a.guard[1] = 1u;
+#endif
     F3_STAMP(41, "s_memtime");
     F3_STAMP(51, "s_memrealtime");
 }
@@ -484,7 +517,11 @@ template <class C, int F3_WAVES>
 hipError_t launch_fwd3_w(const Fwd3Args& a, hipStream_t stream) {
     const size_t lds = ((size_t)a.n_blocks * C::CONST_FLOATS + 2 * (size_t)C::SLOT3) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+#if LSNF_L16_PARTS == 3
     auto kern = a.shape16 ? lsnf_fwd3b_kernel<C, F3_WAVES> : lsnf_fwd3_kernel<C, F3_WAVES>;
+#else
+    auto kern = lsnf_fwd3b_kernel<C, F3_WAVES>;
+#endif
     static unsigned long long lds_ok[2] = {0, 0};
     if (hipError_t e = lsnf_allow_big_lds((const void*)kern, &lds_ok[a.shape16 ? 1 : 0]); e != hipSuccess) return e;
     const unsigned grid = (unsigned)((a.B + 32 * F3_WAVES - 1) / (32 * F3_WAVES));
@@ -499,16 +536,29 @@ hipError_t launch_fwd3(const Fwd3Args& a, hipStream_t stream) {
 }  // namespace
 
 // host-side dispatcher (called from lsnf_api.hip); hipErrorInvalidValue = this geometry is not covered
-hipError_t lsnf_launch_forward3(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
+#ifndef LSNF_FWD3_ENTRY
+#define LSNF_FWD3_ENTRY lsnf_launch_forward3
+#endif
+hipError_t LSNF_FWD3_ENTRY(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                 const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                 float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
-                                int shape16, hipStream_t stream) {
+                                int shape16, unsigned* guard, hipStream_t stream) {
     Fwd3Args a;
     a.shape16 = shape16;
+    a.guard = guard;
+#if LSNF_L16_PARTS == 3
+    if (guard && !shape16) return hipErrorInvalidValue;      // the fix-up pass is the L16 kernel
+#else
+    if (!guard) return hipErrorInvalidValue;
+#endif
     a.stats = stats;
     a.act_saved = act_saved ? act_saved + (size_t)first_block * lsnf_act_layout(B, g.HT, g.WT).per_block : nullptr;
     a.consts = plan + g.off_fwd_const + (size_t)first_block * g.fwd_const_floats;
+#if LSNF_L16_PARTS == 3
     a.panels3 = plan + (shape16 ? g.off_f3b_panels : g.off_f3_panels) + (size_t)first_block * g.f3_block_floats;
+#else
+    a.panels3 = plan + g.off_f2h_panels + (size_t)first_block * g.f2h_block_floats;
+#endif
     a.z_in = z_in; a.objective = objective; a.z_out = z_out; a.logdet_out = logdet_out; a.ll_out = ll_out;
     a.z_saved = z_saved; a.B = B; a.nz = g.nz; a.half = g.half; a.n_blocks = n_blocks; a.vec4 = vec4;
     a.stamps = nullptr;

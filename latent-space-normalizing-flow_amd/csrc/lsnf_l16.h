@@ -12,12 +12,39 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// the three bf16 terms of one k-step (16 features of one 32-sample tile), B-operand order
-struct Split3 { bf16x8 p[3]; };
+// Operand split of the L16 kernels, chosen per translation unit:
+//   LSNF_L16_PARTS 3 (default): three bf16 terms per operand, the six products of weight 2^-9(i+j) <= 2^-18 kept
+//   LSNF_L16_PARTS 2          : two fp16 terms per operand (11 + 11 significand bits), the three products (1,1) (1,2) (2,1)
+//                               kept: dropped w2*x2 <= 2^-22 |w||x|; operands must stay inside fp16's range (|x| < 65504)
+#ifndef LSNF_L16_PARTS
+#define LSNF_L16_PARTS 3
+#endif
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#if LSNF_L16_PARTS == 3
+typedef bf16x8 l16_op8;
+#define LSNF_L16_TERMS(M) M(2, 0) M(0, 2) M(1, 1) M(1, 0) M(0, 1) M(0, 0)
+#define LSNF_L16_NTERMS 6
+#define LSNF_L16_MFMA __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#else
+typedef f16x8 l16_op8;
+#define LSNF_L16_TERMS(M) M(1, 0) M(0, 1) M(0, 0)
+#define LSNF_L16_NTERMS 3
+#define LSNF_L16_MFMA __builtin_amdgcn_mfma_f32_16x16x32_f16
+#endif
+// floats of one (n-tile, k-tile) weight fragment: 2 feature halves x PARTS x 1 KiB
+#define L16_FRAG_FLOATS (512 * LSNF_L16_PARTS)
+
+// the terms of one k-step (16 features of one 32-sample tile), B-operand order
+struct Split3 { l16_op8 p[LSNF_L16_PARTS]; };
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
     const f32x2v v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));      // v_cvt_pk_bf16_f32 (RNE)
+}
+__device__ __forceinline__ f16x2 pk_f16(float a, float b) {
+    const f32x2v v = {a, b};
+    return __builtin_convertvector(v, f16x2);                                     // round to nearest even
 }
 // LDS-DMA of KB KiB (1 KiB per wave-instruction), as lsnf_issue_panel
 template <int KB, int NW>
@@ -48,7 +75,7 @@ struct Pipe3 {
         return ready;
     }
 };
-__device__ __forceinline__ constexpr int first_kib(int NT, int KT) { return 6 * KT * (NT >= 2 ? 2 : 1); }
+__device__ __forceinline__ constexpr int first_kib(int NT, int KT) { return 2 * LSNF_L16_PARTS * KT * (NT >= 2 ? 2 : 1); }
 
 // the six kept terms (weight part, activation part), smallest first
 #define LSNF_F3_TERMS(M) M(2, 0) M(0, 2) M(1, 1) M(1, 0) M(0, 1) M(0, 0)
@@ -120,21 +147,27 @@ __device__ __forceinline__ f32x16 l16_bias_init(const float* cst, int g) {
 }
 // one activation tile -> the three bf16 terms of its two sample tiles (B operands of K = 32: slots 0..3 from ft = 0, 4..7 from ft = 1)
 __device__ __forceinline__ void l16_split_tile(const f32x16& x, Split3& s0, Split3& s1) {
-    u32x4 w[2][3];
+    u32x4 w[2][LSNF_L16_PARTS];
 #pragma unroll
     for (int st = 0; st < 2; ++st)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {          // pair q: ft = q >> 1, registers 2*(q&1), 2*(q&1)+1
             const int b = (2 * (q >> 1) + st) * 4 + 2 * (q & 1);
             float a = x[b], c = x[b + 1];
+#if LSNF_L16_PARTS == 3
             const unsigned p1 = pk_bf16(a, c);
             a -= __builtin_bit_cast(float, p1 << 16); c -= __builtin_bit_cast(float, p1 & 0xffff0000u);
             const unsigned p2 = pk_bf16(a, c);
             a -= __builtin_bit_cast(float, p2 << 16); c -= __builtin_bit_cast(float, p2 & 0xffff0000u);
             w[st][0][q] = p1; w[st][1][q] = p2; w[st][2][q] = pk_bf16(a, c);
+#else
+            const f16x2 h1 = pk_f16(a, c);
+            a -= (float)h1[0]; c -= (float)h1[1];
+            w[st][0][q] = __builtin_bit_cast(unsigned, h1); w[st][1][q] = __builtin_bit_cast(unsigned, pk_f16(a, c));
+#endif
         }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { s0.p[i] = __builtin_bit_cast(bf16x8, w[0][i]); s1.p[i] = __builtin_bit_cast(bf16x8, w[1][i]); }
+    for (int i = 0; i < LSNF_L16_PARTS; ++i) { s0.p[i] = __builtin_bit_cast(l16_op8, w[0][i]); s1.p[i] = __builtin_bit_cast(l16_op8, w[1][i]); }
 }
 template <int KT>
 __device__ __forceinline__ void l16_split_tiles(const f32x16* x, Split3* out) {   // out[2*KT]: [kt][st]
@@ -146,13 +179,13 @@ __device__ __forceinline__ void l16_split_tiles(const f32x16* x, Split3* out) { 
 // parts of 16 output features) feed 12 MFMAs (6 terms x 2 sample tiles); the next step's reads are issued first.
 template <int KT, int NTILES>
 __device__ __forceinline__ void l16_panel_mma3(f32x16& acc0, f32x16& acc1, const Split3* in, const float* lbuf, int lane) {
-    const bf16x8* wp = reinterpret_cast<const bf16x8*>(lbuf) + lane;
+    const l16_op8* wp = reinterpret_cast<const l16_op8*>(lbuf) + lane;
     constexpr int STEPS = 2 * KT * NTILES;
     __builtin_amdgcn_sched_barrier(0);
-    bf16x8 a[3];
+    l16_op8 a[LSNF_L16_PARTS];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) a[p] = wp[p * 64];
-    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+    for (int p = 0; p < LSNF_L16_PARTS; ++p) a[p] = wp[p * 64];
+    __builtin_amdgcn_sched_group_barrier(0x100, LSNF_L16_PARTS, 0);
     f32x4v c[2][2][2];                                   // [tile][ft][st]
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft)
@@ -163,22 +196,22 @@ __device__ __forceinline__ void l16_panel_mma3(f32x16& acc0, f32x16& acc1, const
 #pragma unroll
     for (int idx = 0; idx < STEPS; ++idx) {
         const int tile = idx / (2 * KT), kt = (idx % (2 * KT)) / 2, ft = idx & 1;
-        bf16x8 na[3];
+        l16_op8 na[LSNF_L16_PARTS];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) na[p] = a[p];
+        for (int p = 0; p < LSNF_L16_PARTS; ++p) na[p] = a[p];
         if (idx + 1 < STEPS) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) na[p] = wp[((idx + 1) * 3 + p) * 64];
+            for (int p = 0; p < LSNF_L16_PARTS; ++p) na[p] = wp[((idx + 1) * LSNF_L16_PARTS + p) * 64];
         }
 #define LSNF_F3_MMA(WI, XI)                                                                                                        \
-        c[tile][ft][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[WI], in[2 * kt + 0].p[XI], c[tile][ft][0], 0, 0, 0);         \
-        c[tile][ft][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[WI], in[2 * kt + 1].p[XI], c[tile][ft][1], 0, 0, 0);
-        LSNF_F3_TERMS(LSNF_F3_MMA)
+        c[tile][ft][0] = LSNF_L16_MFMA(a[WI], in[2 * kt + 0].p[XI], c[tile][ft][0], 0, 0, 0);         \
+        c[tile][ft][1] = LSNF_L16_MFMA(a[WI], in[2 * kt + 1].p[XI], c[tile][ft][1], 0, 0, 0);
+        LSNF_L16_TERMS(LSNF_F3_MMA)
 #undef LSNF_F3_MMA
-        if (idx + 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        if (idx + 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, LSNF_L16_PARTS, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * LSNF_L16_NTERMS, 0);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) a[p] = na[p];
+        for (int p = 0; p < LSNF_L16_PARTS; ++p) a[p] = na[p];
     }
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft)
@@ -197,7 +230,7 @@ __device__ __forceinline__ void l16_gemm_stage3(Pipe& pipe, const float* gsrc, c
         const float* lb;
         if constexpr (q + 1 < NSP) {
             constexpr int cn = (NT - (t0 + 2) >= 2) ? 2 : 1;
-            lb = pipe.template acquire<6 * KT * cn>(gsrc + (t0 + 2) * KT * LSNF_FRAG3_FLOATS);
+            lb = pipe.template acquire<2 * LSNF_L16_PARTS * KT * cn>(gsrc + (t0 + 2) * KT * L16_FRAG_FLOATS);
         } else {
             lb = pipe.template acquire<NEXT_KIB>(gnext);
         }

@@ -28,6 +28,9 @@
 // i.e. k-slot j of lane-half h in k-step s is accumulator register 8*s + j of that lane-half -- an output tile
 // converted to bf16 pairs in register order is directly the next GEMM's B operand.
 #define LSNF_FRAG3_FLOATS 1536 /* 2 k-steps x 3 parts x 1 KiB, in 4-byte units */
+#define LSNF_GUARD_WORDS 4
+#define LSNF_F16_GUARD_MAX 65504.0f /* |x| >= this does not survive the round-to-nearest fp16 conversion */
+#define LSNF_FRAG2H_FLOATS 1024 /* fp16 two-term split: 2 feature halves x 2 parts x 1 KiB */
 // The same three bf16 matrices once more in the A-operand order of v_mfma_f32_16x16x32_bf16 (lsnf_fwd3.hip, 16x16 variant;
 // that shape sustains a higher clock on real data).  Lane layout of that variant: a wave's 32 samples are two sample
 // tiles st of 16, lane = (n = lane & 15 -> sample 16*st + n, g = lane >> 4); a 32-feature activation tile is 16 registers
@@ -59,6 +62,10 @@ struct LsnfGeo {
     size_t off_b3b_panels;
     int i3_block_floats;        // inverse panel I1 likewise
     size_t off_i3b_panels;
+    int f2h_block_floats;       // forward panels as two fp16 matrices (LSNF_MATH_FP16X2), 16x16x32 operand order
+    size_t off_f2h_panels;
+    size_t off_guard;           // LSNF_GUARD_WORDS 32-bit words of the fp16 range guard (lsnf_fwd2h.hip): [0] weights outside
+                                // fp16's range (set by prepare), [1] an operand overflowed in the last fp16 forward, [2] ticket
     size_t total_floats;
 };
 
@@ -141,6 +148,10 @@ static inline int lsnf_geo_init(LsnfGeo* g, int nz, int width, int depth, int co
     g->i3_block_floats = LSNF_FRAG3_FLOATS * (NZT * NZT);
     g->off_i3b_panels = o; o += (size_t)depth * g->i3_block_floats;
     o = (o + 255) & ~(size_t)255;
+    g->f2h_block_floats = LSNF_FRAG2H_FLOATS * (NZT * NZT + WT * HT + WT * WT + 2 * HT * WT);
+    g->off_f2h_panels = o; o += (size_t)depth * g->f2h_block_floats;
+    o = (o + 255) & ~(size_t)255;
+    g->off_guard = o; o += 256;
     g->total_floats = o;
     return 0;
 }

@@ -262,6 +262,26 @@ __device__ static inline void frag3b_decode(int q, int KT, int* k0, int* k1, int
     *k1 = 32 * kt + (j1 < 4 ? 4 * kg + j1 : 16 + 4 * kg + j1 - 4);
     *n = 32 * nt + 16 * ft + (lane & 15);
 }
+// the fp16 two-term stream (lsnf_fwd2h.hip): same operand order, parts 0..1
+__device__ static inline void frag2h_decode(int q, int KT, int* k0, int* k1, int* n, int* part) {
+    const int per_panel = KT * LSNF_FRAG2H_FLOATS;
+    const int nt = q / per_panel; int r = q % per_panel;
+    const int kt = r / LSNF_FRAG2H_FLOATS; r %= LSNF_FRAG2H_FLOATS;
+    const int fp = r / 256; r %= 256;                 // ft*2 + part
+    const int ft = fp / 2, lane = r / 4, jw = r % 4;
+    *part = fp % 2;
+    const int j0 = 2 * jw, j1 = 2 * jw + 1, kg = lane >> 4;
+    *k0 = 32 * kt + (j0 < 4 ? 4 * kg + j0 : 16 + 4 * kg + j0 - 4);
+    *k1 = 32 * kt + (j1 < 4 ? 4 * kg + j1 : 16 + 4 * kg + j1 - 4);
+    *n = 32 * nt + 16 * ft + (lane & 15);
+}
+// part p (0..1) of the error-free split w = w1 + w2 into round-to-nearest fp16 terms, as its 16-bit pattern
+__device__ static inline unsigned f16_part_bits(double v, int part) {
+    float r = (float)v;
+    _Float16 h = (_Float16)r;
+    if (part == 1) h = (_Float16)(r - (float)h);
+    return (unsigned)__builtin_bit_cast(unsigned short, h);
+}
 // round-to-nearest-even bf16 of a float, as its 16-bit pattern (finite inputs)
 __device__ static inline unsigned bf16_rne_bits(float x) {
     const unsigned u = __float_as_uint(x);
@@ -401,6 +421,21 @@ __global__ __launch_bounds__(256) void lsnf_pack_kernel(LsnfParamPtrs pp, LsnfGe
             dst[q] = bf16_part_bits(fwd_mat(g, P, stage, k0, n), part) | (bf16_part_bits(fwd_mat(g, P, stage, k1, n), part) << 16);
         }
     }
+    // ---- fp16 two-term forward panels (LSNF_MATH_FP16X2), 16x16x32 operand order
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < g.f2h_block_floats; q += gridDim.x * 256) {
+        unsigned* dst = reinterpret_cast<unsigned*>(plan + g.off_f2h_panels + (size_t)blk * g.f2h_block_floats);
+        int r = q, k0, k1, n, part, stage, KT;
+        const int s1 = LSNF_FRAG2H_FLOATS * NZT * NZT, s2 = LSNF_FRAG2H_FLOATS * WT * HT, s3 = LSNF_FRAG2H_FLOATS * WT * WT;
+        if (r < s1) { stage = 1; KT = NZT; }
+        else if ((r -= s1) < s2) { stage = 2; KT = HT; }
+        else if ((r -= s2) < s3) { stage = 3; KT = WT; }
+        else { r -= s3; stage = 4; KT = WT; }
+        frag2h_decode(r, KT, &k0, &k1, &n, &part);
+        const double w0 = fwd_mat(g, P, stage, k0, n), w1 = fwd_mat(g, P, stage, k1, n);
+        if (!(fabs(w0) < (double)LSNF_F16_GUARD_MAX) || !(fabs(w1) < (double)LSNF_F16_GUARD_MAX))     // also NaN
+            reinterpret_cast<unsigned*>(plan + g.off_guard)[0] = 1u;                                  // fp16 forward unusable: lsnf_fwd2h.hip defers to bf16x3
+        dst[q] = f16_part_bits(w0, part) | (f16_part_bits(w1, part) << 16);
+    }
 }
 
 size_t lsnf_prep_scratch_bytes(int nz, int depth) { return sizeof(double) * scratch_block_doubles(nz) * (size_t)depth; }
@@ -415,6 +450,7 @@ hipError_t lsnf_launch_prepare(const LsnfGeo& g, const float* const* params_host
     if (e != hipSuccess) return e;
     const int per_block = g.fwd_const_floats + g.fwd_block_floats + g.inv_const_floats + g.inv_block_floats +
                           g.bwd_block_floats + g.nz * g.nz + 2 * g.f3_block_floats + g.b3_block_floats + g.i3_block_floats;
+    if (hipError_t em = hipMemsetAsync(plan + g.off_guard, 0, sizeof(unsigned) * LSNF_GUARD_WORDS, stream); em != hipSuccess) return em;
     int gx = (per_block + 255) / 256;
     if (gx > 512) gx = 512;
     hipLaunchKernelGGL(lsnf_pack_kernel, dim3(gx, g.depth), dim3(256), 0, stream, pp, g, (const double*)scratch, plan);

@@ -163,7 +163,7 @@ def set_small_batch_max(rows: int) -> int:
     return _lib.load().lsnf_set_small_batch_max(int(rows))
 
 
-MATH_FP32, MATH_BF16X3, MATH_BF16X3_32 = 0, 1, 2
+MATH_FP32, MATH_BF16X3, MATH_BF16X3_32, MATH_FP16X2 = 0, 1, 2, 3
 
 
 def set_math_mode(mode: int) -> int:

@@ -96,7 +96,7 @@ def test_forward_vs_oracle_ragged(lsnf, kernels, gpu_device, nz, width, B):
     assert (z1.cpu() - z1r).abs().max().item() <= Z_ABS * max(1.0, z1r.abs().max().item())
 
 
-@pytest.mark.parametrize("math", ["fp32", "bf16x3", "bf16x3_32"])
+@pytest.mark.parametrize("math", ["fp32", "bf16x3", "bf16x3_32", "fp16x2"])
 def test_full_size_properties(lsnf, gpu_device, math):
     """BASELINE.json's full size (nz=128, w=64, B=65536), both arithmetic modes: size-independent properties.
     (a) row independence: the first 4096 rows of the big launch equal a 4096-row launch bit for bit;
@@ -109,7 +109,7 @@ def test_full_size_properties(lsnf, gpu_device, math):
     zd = z.to(gpu_device)
     prev = lsnf.flow.set_small_batch_max(8192)
     prev_math = lsnf.flow.set_math_mode({"fp32": lsnf.flow.MATH_FP32, "bf16x3": lsnf.flow.MATH_BF16X3,
-                                         "bf16x3_32": lsnf.flow.MATH_BF16X3_32}[math])
+                                         "bf16x3_32": lsnf.flow.MATH_BF16X3_32, "fp16x2": lsnf.flow.MATH_FP16X2}[math])
     z1, ld, ll, _ = lsnf.forward(plan, zd)                                   # throughput kernel
     z1s, lds, lls, _ = lsnf.forward(plan, zd[:16384].contiguous())           # throughput kernel, fewer rows
     assert torch.equal(z1[:16384], z1s) and torch.equal(ll[:16384], lls) and torch.equal(ld[:16384], lds)
@@ -140,14 +140,67 @@ def test_split_bf16_is_fp32_faithful(lsnf, gpu_device, name):
     _, _, ll64 = O.flow_log_prob(O.to_dtype(p, torch.float64), z.double())
     prev = lsnf.flow.set_small_batch_max(0)
     err = {}
-    for mode, tag in ((lsnf.flow.MATH_FP32, "fp32"), (lsnf.flow.MATH_BF16X3, "bf16x3"), (lsnf.flow.MATH_BF16X3_32, "bf16x3_32")):
+    for mode, tag in ((lsnf.flow.MATH_FP32, "fp32"), (lsnf.flow.MATH_BF16X3, "bf16x3"), (lsnf.flow.MATH_BF16X3_32, "bf16x3_32"),
+                      (lsnf.flow.MATH_FP16X2, "fp16x2")):
         prev_math = lsnf.flow.set_math_mode(mode)
         _, _, ll, _ = lsnf.forward(plan, z.to(gpu_device))
         lsnf.flow.set_math_mode(prev_math)
         err[tag] = ((ll.cpu().double() - ll64).abs() / ll64.abs().clamp_min(1.0)).max().item()
     lsnf.flow.set_small_batch_max(prev)
+    print(name, err)
     assert max(err.values()) <= 2e-6, err
     assert max(err["bf16x3"], err["bf16x3_32"]) <= 2.0 * err["fp32"] + 1e-7, err
+    # the two-way fp16 split (lsnf_fwd2h.hip) drops terms of 2^-22 |w||x|: same class, slightly looser bound
+    assert err["fp16x2"] <= 3.0 * err["fp32"] + 1e-7, err
+
+
+def test_fp16_split_range_guard(lsnf, gpu_device):
+    """LSNF_MATH_FP16X2 has fp16's exponent range; an operand (or a folded weight) at or beyond 65504 makes the fp16
+    kernel raise its flag and the bf16x3 pass queued behind it recompute the launch: the results are then bit-for-bit
+    those of LSNF_MATH_BF16X3 (no inf / NaN, no silently clipped ReLU input), the flag is lowered again, and the
+    in-kernel batch sums are those of the recomputation."""
+    nz, width, depth, B = 128, 64, 5, 33000
+    p = O.init_params(nz, width, depth, seed=21)
+    plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
+    g = torch.Generator().manual_seed(22)
+    z = torch.randn(B, nz, generator=g)
+    z_big = z.clone()
+    z_big[12345] *= 3.0e4                       # one row far outside fp16's range (|z| up to ~1e5)
+    prev_small = lsnf.flow.set_small_batch_max(0)
+    prev = lsnf.flow.set_math_mode(lsnf.flow.MATH_BF16X3)
+    try:
+        stats = lsnf.flow.new_stats(gpu_device)
+        ref_big = lsnf.forward(plan, z_big.to(gpu_device), stats=stats)
+        ref_sum = stats[4].item()
+        lsnf.flow.set_math_mode(lsnf.flow.MATH_FP16X2)
+        h_small = lsnf.forward(plan, z.to(gpu_device))
+        got_big = lsnf.forward(plan, z_big.to(gpu_device), stats=stats)
+        assert torch.isfinite(got_big[2]).all()
+        for a, b in zip(ref_big[:3], got_big[:3]):
+            assert torch.equal(a, b)
+        assert stats[4].item() == ref_sum and stats[6].item() == B
+        h_again = lsnf.forward(plan, z.to(gpu_device), stats=stats)           # flag lowered: the fp16 kernel's own results again
+        for a, b in zip(h_small[:3], h_again[:3]):
+            assert torch.equal(a, b)
+        assert abs(stats[4].item() - h_again[2].double().sum().item()) <= 1e-9 * abs(stats[4].item())
+        lsnf.flow.set_math_mode(lsnf.flow.MATH_BF16X3)
+        b_small = lsnf.forward(plan, z.to(gpu_device))
+        assert not torch.equal(b_small[2], h_small[2])                        # (the two modes do differ in the last bits)
+        assert ((b_small[2] - h_small[2]).abs() / b_small[2].abs().clamp_min(1.0)).max().item() <= 2e-6
+        # folded weights outside fp16's range (actnorm logs = 5 -> exp(15)): prepare marks the plan, every launch is recomputed
+        q = dict(p)
+        k = O.block_prefix(2) + "actnorm.logs"
+        q[k] = q[k].clone(); q[k][0, 7] = 5.0
+        plan2 = lsnf.prepare(lsnf.params_from_state_dict(q, depth, gpu_device), nz, width, depth)
+        ref2 = lsnf.forward(plan2, z.to(gpu_device))
+        lsnf.flow.set_math_mode(lsnf.flow.MATH_FP16X2)
+        got2 = lsnf.forward(plan2, z.to(gpu_device))
+        assert torch.isfinite(got2[2]).all()
+        for a, b in zip(ref2[:3], got2[:3]):
+            assert torch.equal(a, b)
+    finally:
+        lsnf.flow.set_math_mode(prev)
+        lsnf.flow.set_small_batch_max(prev_small)
 
 
 def test_errors_are_loud(lsnf, gpu_device):
@@ -200,11 +253,14 @@ def test_split_bf16_dynamic_range(lsnf, gpu_device, z_scale, w_scale):
     _, _, ll64 = O.flow_log_prob(O.to_dtype(p, torch.float64), z[idx].double())
     plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
     err = {}
-    for mode, tag in ((lsnf.flow.MATH_FP32, "fp32"), (lsnf.flow.MATH_BF16X3, "bf16x3"), (lsnf.flow.MATH_BF16X3_32, "bf16x3_32")):
+    for mode, tag in ((lsnf.flow.MATH_FP32, "fp32"), (lsnf.flow.MATH_BF16X3, "bf16x3"), (lsnf.flow.MATH_BF16X3_32, "bf16x3_32"),
+                      (lsnf.flow.MATH_FP16X2, "fp16x2")):
         prev = lsnf.flow.set_math_mode(mode)
         _, _, ll, _ = lsnf.forward(plan, z.to(gpu_device))
         lsnf.flow.set_math_mode(prev)
         assert torch.isfinite(ll).all()
         err[tag] = ((ll.cpu()[idx].double() - ll64).abs() / ll64.abs().clamp_min(1.0)).max().item()
+    print(z_scale, w_scale, err)
     assert max(err.values()) <= 1e-5, err
     assert max(err["bf16x3"], err["bf16x3_32"]) <= 2.0 * err["fp32"] + 1e-7, err
+    assert err["fp16x2"] <= 3.0 * err["fp32"] + 1e-7, err
