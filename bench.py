@@ -101,9 +101,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank logic on a box with fewer GPUs than ranks)")
-    ap.add_argument("--math", choices=["bf16x3", "fp32"], default="bf16x3",
-                    help="arithmetic of the forward's GEMMs: bf16x3 = error-free three-way bf16 split on the bf16 matrix "
-                         "pipe (fp32-class accuracy, the library default); fp32 = fp32 MFMA")
+    ap.add_argument("--math", choices=["fp16x2", "bf16x3", "fp32"], default="fp16x2",
+                    help="arithmetic of the forward's GEMMs: fp16x2 = two-term fp16 split, three fp16 MFMAs per product, "
+                         "range-guarded by a bf16x3 fix-up pass (fp32-class accuracy, the library default); bf16x3 = "
+                         "error-free three-way bf16 split, six bf16 MFMAs per product; fp32 = fp32 MFMA")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the independent steps alternate over (2: the head of step i+1 overlaps the tail of step i)")
     args = ap.parse_args()
@@ -126,7 +127,7 @@ def main():
             dist.init_process_group(args.backend)
 
     import lsnf_amd
-    MATH = {"fp32": lsnf_amd.flow.MATH_FP32, "bf16x3": lsnf_amd.flow.MATH_BF16X3}
+    MATH = {"fp32": lsnf_amd.flow.MATH_FP32, "bf16x3": lsnf_amd.flow.MATH_BF16X3, "fp16x2": lsnf_amd.flow.MATH_FP16X2}
     lsnf_amd.flow.set_math_mode(MATH[args.math])
     weights = synth_weights(1)
     plan = lsnf_amd.prepare([w.to(dev) for w in weights], NZ, WIDTH, DEPTH)
@@ -203,11 +204,15 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / kl
-    other = "fp32" if args.math == "bf16x3" else "bf16x3"
-    kern_ms_other = kernel_ms(other)          # the other arithmetic mode, reported beside the measured one
-    ll_other = ll.clone()
+    others = {}
+    for other in [m for m in ("fp32", "bf16x3", "fp16x2") if m != args.math]:   # the other arithmetic modes, reported beside the measured one
+        others[other] = {"kernel_ms": kernel_ms(other)}
+        others[other]["ll"] = ll.clone()
     kern_ms = kernel_ms(args.math)            # also leaves the library in the measured mode
-    ll_rel_between_modes = ((ll - ll_other).abs() / ll.abs().clamp_min(1.0)).max().item()
+    for other in others:
+        ll_o = others[other].pop("ll")
+        others[other]["samples_per_s_kernel_only"] = B_PER_GPU / (others[other]["kernel_ms"] * 1e-3)
+        others[other]["max_rel_ll_difference_to_measured_mode"] = ((ll - ll_o).abs() / ll.abs().clamp_min(1.0)).max().item()
     # prepare (weight folding + fp64 Gauss-Jordan), amortised over the Langevin loop in production
     p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     wd = [w.to(dev) for w in weights]
@@ -222,7 +227,17 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = world * B_PER_GPU * args.steps / elapsed
         tflops = FLOP_PER_SAMPLE * B_PER_GPU / (kern_ms * 1e-3) / 1e12          # algorithmic (fp32-equivalent) rate
-        if args.math == "bf16x3":   # the matrix pipe executes 6 bf16 MFMA flops per algorithmic flop: price THAT against the bf16 peak
+        if args.math == "fp16x2":   # 3 fp16 MFMA flops per algorithmic flop, priced against the dense fp16 peak (= the bf16 one)
+            rl = {"bound": "mfma", "achieved": 3 * tflops, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                  "frac": 3 * tflops / PEAK_BF16_MFMA_TFLOPS, "kernel": "lsnf_fwd2h_kernel<Fwd3Cfg<2,2>, 8>",
+                  "note": "executed fp16 MFMA flops (3 per algorithmic flop: operands split into two fp16 terms, products "
+                          "w1x1 + w1x2 + w2x1) vs the dense fp16 peak; algorithmic_tflops is the fp32-equivalent rate, 1.0 of "
+                          "the fp32 MFMA peak would be 157.3.  kernel_ms is measured around the launch PAIR the mode issues "
+                          "(the fp16 kernel and the bf16x3 fix-up pass behind it, which exits at once unless an operand left "
+                          "fp16's range: ~2 us).  The matrix pipe is busy about half of the kernel: the rest is the operand "
+                          "split (2.5 VALU per element), the coupling epilogue and the z rows in / out, none of which "
+                          "overlap MFMA issue on a SIMD (DESIGN.md section 5)"}
+        elif args.math == "bf16x3":   # the matrix pipe executes 6 bf16 MFMA flops per algorithmic flop: price THAT against the bf16 peak
             rl = {"bound": "mfma", "achieved": SPLIT_MFMA_PER_PRODUCT * tflops, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                   "frac": SPLIT_MFMA_PER_PRODUCT * tflops / PEAK_BF16_MFMA_TFLOPS, "kernel": "lsnf_fwd3b_kernel<Fwd3Cfg<2,2>, 8>",
                   "note": "executed bf16 MFMA flops (6 per algorithmic flop) vs the dense bf16 peak; algorithmic_tflops is "
@@ -245,7 +260,7 @@ def main():
             "metric": "latent-samples/sec through flow+logdet, nz=128 B=65536",
             "value": value, "unit": "latent-samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16x3" if args.math == "bf16x3" else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"fp16x2": "fp16x2", "bf16x3": "bf16x3", "fp32": "f32"}[args.math], "data": "synthetic",
             "config": {"workload": "CIFAR-10 flow prior nz=128 f_width=64 f_depth=5 affine, forward+logdet+log-prob, "
                                    "B=65536 synthetic z per GPU (BASELINE.json configs[2])",
                        "rows_per_gpu": B_PER_GPU, "global_rows": world * B_PER_GPU,
@@ -253,12 +268,17 @@ def main():
                                        f"{REDUCE_BUCKET} evaluations per collective)") if world > 1 else "single GPU",
                        "streams": n_streams, "clock_ramp_launches_before_warmup": RAMP_LAUNCHES,
                        "prepare_ms_not_in_step": prep_ms,
-                       "math": ("bf16x3: every GEMM operand split error-free into three bf16 terms, six bf16 MFMAs (16x16x32) per product, "
-                                "fp32 accumulation; log-prob error vs float64 equals the fp32-MFMA kernel's (tests/"
-                                "test_gpu_forward.py::test_split_bf16_is_fp32_faithful)") if args.math == "bf16x3" else "fp32 MFMA",
-                       "other_math_mode": {"math": other, "kernel_ms": kern_ms_other,
-                                           "samples_per_s_kernel_only": B_PER_GPU / (kern_ms_other * 1e-3),
-                                           "max_rel_ll_difference_between_modes": ll_rel_between_modes}},
+                       "math": {"fp16x2": "fp16x2: every GEMM operand split into two fp16 terms (11+11 significand bits), three fp16 "
+                                          "MFMAs (16x16x32) per product, fp32 accumulation; dropped terms <= 2^-22|w||x|, log-prob "
+                                          "error vs float64 equals the fp32-MFMA kernel's (tests/test_gpu_forward.py::"
+                                          "test_split_bf16_is_fp32_faithful, ::test_split_bf16_dynamic_range); operands outside "
+                                          "fp16's range are caught in-kernel and the launch recomputed by the bf16x3 kernel "
+                                          "(::test_fp16_split_range_guard)",
+                                "bf16x3": "bf16x3: every GEMM operand split error-free into three bf16 terms, six bf16 MFMAs "
+                                          "(16x16x32) per product, fp32 accumulation; log-prob error vs float64 equals the "
+                                          "fp32-MFMA kernel's (tests/test_gpu_forward.py::test_split_bf16_is_fp32_faithful)",
+                                "fp32": "fp32 MFMA"}[args.math],
+                       "other_math_modes": others},
             "roofline": dict(rl, traffic=traffic, kernel_ms=kern_ms, flop_per_launch=FLOP_PER_SAMPLE * B_PER_GPU,
                              algorithmic_tflops=tflops, fp32_mfma_peak=PEAK_FP32_MFMA_TFLOPS,
                              hbm_frac_secondary=BYTES_PER_SAMPLE_FUSED * B_PER_GPU / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS),

@@ -167,9 +167,11 @@ MATH_FP32, MATH_BF16X3, MATH_BF16X3_32, MATH_FP16X2 = 0, 1, 2, 3
 
 
 def set_math_mode(mode: int) -> int:
-    """Arithmetic of the throughput forward's GEMMs: MATH_FP32 (fp32 MFMA), MATH_BF16X3 (error-free three-way bf16
-    split on the bf16 matrix pipe, fp32-class accuracy; 16x16x32 MFMA) or MATH_BF16X3_32 (the same on the 32x32x16
-    MFMA, kept for comparison).  Returns the previous mode (mode < 0: query)."""
+    """Arithmetic of the GEMMs (include/lsnf_flow.h): MATH_FP16X2 (default: throughput forward on a two-term fp16 split,
+    three fp16 MFMAs per product, range-guarded by a bf16x3 fix-up pass; everything else as MATH_BF16X3), MATH_BF16X3
+    (error-free three-way bf16 split, six bf16 MFMAs per product; 16x16x32 MFMA), MATH_BF16X3_32 (the same on the
+    32x32x16 MFMA, kept for comparison) or MATH_FP32 (fp32 MFMA).  All four are fp32-class in accuracy.
+    Returns the previous mode (mode < 0: query)."""
     return _lib.load().lsnf_set_math_mode(int(mode))
 
 

@@ -164,7 +164,7 @@ def test_default_dispatch_mid_size_batch(lsnf, gpu_device):
     nz, width, depth, B = 100, 64, 5, 10000
     p = O.init_params(nz, width, depth, seed=5)
     plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
-    assert lsnf.flow.set_math_mode(-1) == lsnf.flow.MATH_BF16X3 and lsnf.flow.set_small_batch_max(-1) == 16384
+    assert lsnf.flow.set_math_mode(-1) == lsnf.flow.MATH_FP16X2 and lsnf.flow.set_small_batch_max(-1) == 16384
     z = torch.randn(B, nz, generator=torch.Generator().manual_seed(8))
     z1, ld, ll, saved, act = _fwd(lsnf, plan, z.to(gpu_device), True)
     g_stash = lsnf.backward_z(plan, z1, saved, ll_scale=-1.0, act_saved=act)
@@ -176,3 +176,25 @@ def test_default_dispatch_mid_size_batch(lsnf, gpu_device):
         assert ((g.cpu()[idx] - ref)[ok].norm() / ref[ok].norm()).item() <= 1e-5
     _, _, llr = O.flow_log_prob(p, z[idx])
     assert ((ll.cpu()[idx] - llr).abs() / llr.abs()).max().item() <= 1e-5
+
+
+def test_default_dispatch_large_batch(lsnf, gpu_device):
+    """Default dispatch at 40 000 rows: the fp16x2 throughput forward (lsnf_fwd2h.hip) writes z_saved and the activation
+    stash, the bf16x3 throughput backward (lsnf_bwd3.hip) reads them; the Langevin step built from the two matches the
+    oracle on rows away from a ReLU kink."""
+    nz, width, depth, B = 128, 64, 5, 40000
+    p = O.init_params(nz, width, depth, seed=6)
+    plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
+    assert lsnf.flow.set_math_mode(-1) == lsnf.flow.MATH_FP16X2
+    z = torch.randn(B, nz, generator=torch.Generator().manual_seed(9))
+    z1, ld, ll, saved, act = _fwd(lsnf, plan, z.to(gpu_device), True)
+    g_stash = lsnf.backward_z(plan, z1, saved, ll_scale=-1.0, act_saved=act)
+    idx = torch.arange(5, B, 211)
+    ref = O.grad_neg_sum_ll_wrt_z(p, z[idx])
+    ok = O.relu_margin(p, z[idx]) > KINK
+    assert ((g_stash.cpu()[idx] - ref)[ok].norm() / ref[ok].norm()).item() <= 1e-5
+    _, _, llr = O.flow_log_prob(p, z[idx])
+    assert ((ll.cpu()[idx] - llr).abs() / llr.abs()).max().item() <= 1e-5
+    zn, ll2, _, _ = lsnf.langevin_step(plan, z.to(gpu_device), None, None, 0.1)
+    zr = z[idx].double() - 0.005 * ref.double()
+    assert ((zn.cpu()[idx].double() - zr)[ok].abs().max() / zr.abs().max()).item() <= 2e-5

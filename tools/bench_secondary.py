@@ -45,9 +45,13 @@ for (tag, nz, w, B) in [("C2/C4 SVHN/CelebA nz=100 w=64 B=100", 100, 64, 100), (
     r = {"config": tag, "B": B}
     r["forward_logprob_us"] = timeit(lambda: lsnf_amd.forward(plan, z), n)
     if B > 16384:
-        pm = lsnf_amd.flow.set_math_mode(1 - lsnf_amd.flow.set_math_mode(-1))
-        r["forward_logprob_other_math_mode_us"] = timeit(lambda: lsnf_amd.forward(plan, z), n)
-        r["default_math_mode"] = "bf16x3" if pm == 1 else "fp32"
+        names = {0: "fp32", 1: "bf16x3", 2: "bf16x3_32", 3: "fp16x2"}
+        pm = lsnf_amd.flow.set_math_mode(-1)
+        r["default_math_mode"] = names[pm]
+        for om in (0, 1, 3):
+            if om != pm:
+                lsnf_amd.flow.set_math_mode(om)
+                r[f"forward_logprob_{names[om]}_us"] = timeit(lambda: lsnf_amd.forward(plan, z), n)
         lsnf_amd.flow.set_math_mode(pm)
     z1, ld, ll, saved = lsnf_amd.forward(plan, z, save_for_backward=True)
     r["forward_saving_us"] = timeit(lambda: lsnf_amd.forward(plan, z, save_for_backward=True), n)

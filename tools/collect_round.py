@@ -7,6 +7,7 @@ R, P = os.path.join(ROOT, "gpurun_out", "round"), os.path.join(ROOT, "profiles")
 last = lambda f: open(f).read().strip().splitlines()[-1] + "\n"
 open(os.path.join(P, f"{tag}_bench.json"), "w").write(last(os.path.join(R, "bench.json")))
 open(os.path.join(P, f"{tag}_bench_fp32.json"), "w").write(last(os.path.join(R, "bench_fp32.json")))
+open(os.path.join(P, f"{tag}_bench_bf16x3.json"), "w").write(last(os.path.join(R, "bench_bf16x3.json")))
 shutil.copy(os.path.join(R, "prof", "bench_kernel_stats.csv"), os.path.join(P, f"{tag}_bench_kernel_stats.csv"))
 os.makedirs(os.path.join(P, f"{tag}_pmc"), exist_ok=True)
 for p in ("p1", "p2", "p3", "p4"):
@@ -15,16 +16,23 @@ shutil.copy(os.path.join(R, "secondary.json"), os.path.join(P, f"{tag}_secondary
 shutil.copy(os.path.join(R, "train_configs.jsonl"), os.path.join(P, f"{tag}_train_configs.jsonl"))
 rows = list(csv.DictReader(open(os.path.join(R, "prof", "bench_kernel_trace.csv"))))
 out = {}
-for key, name in (("fwd3", "lsnf_fwd3b_kernel<Fwd3Cfg<2,2>, 8>"), ("lsnf_fwd_kernel", "lsnf_fwd_kernel<FwdCfg<2,2>, 8>")):
+for key, name in (("lsnf_fwd2h", "lsnf_fwd2h_kernel<Fwd3Cfg<2,2>, 8>"), ("lsnf_fwd3b", "lsnf_fwd3b_kernel<Fwd3Cfg<2,2>, 8>"),
+                  ("lsnf_fwd_kernel", "lsnf_fwd_kernel<FwdCfg<2,2>, 8>")):
     rr = sorted((r for r in rows if key in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
-    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rr]
+    d_all = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rr]
+    d = [x for x in d_all if x > 20.0]                 # full runs (the fp16 mode also queues early-exit fix-up launches of fwd3b)
     out[name] = {"dispatches_in_trace": len(d), "kernel_only_loop_last_200_avg_us": sum(d[-200:]) / 200, "min_us": min(d[-200:]), "max_us": max(d[-200:])}
+    if key == "lsnf_fwd3b":
+        e = [x for x in d_all if x <= 20.0]
+        if e:
+            out["lsnf_fwd3b_kernel as the early-exit fix-up pass behind lsnf_fwd2h_kernel"] = {
+                "dispatches_in_trace": len(e), "kernel_only_loop_last_200_avg_us": sum(e[-200:]) / min(200, len(e)), "min_us": min(e), "max_us": max(e)}
 out["note"] = ("per-dispatch durations from rocprofv3 --kernel-trace of `python3 bench.py --steps 300 --warmup 100 --no-cpu-baseline`; "
                "the timed steps alternate over 2 HIP streams, so their kernels overlap and the all-dispatch average of the "
                "kernel_stats csv is NOT a kernel duration; bench.py's roofline uses its single-stream kernel-only loop "
                "(the last 200 dispatches of each kernel), which is what is averaged here")
 json.dump(out, open(os.path.join(P, f"{tag}_kernel_only_from_trace.json"), "w"), indent=1)
-subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_traffic.py"), os.path.join(R, "pmc"), "bf16x3"], cwd=ROOT, check=True)
+subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_traffic.py"), os.path.join(R, "pmc"), "fp16x2"], cwd=ROOT, check=True)
 b = json.loads(last(os.path.join(R, "bench.json")))
 print(tag, "value %.4g" % b["value"], "ms/step %.4f" % b["ms_per_step"], "kernel_ms %.4f" % b["roofline"]["kernel_ms"], "frac %.3f" % b["roofline"]["frac"],
-      "| fp32 kernel_ms %.4f" % b["config"]["other_math_mode"]["kernel_ms"], "| trace", {k: round(v["kernel_only_loop_last_200_avg_us"], 1) for k, v in out.items() if k != "note"})
+      "| others", {k: round(v["kernel_ms"], 4) for k, v in b["config"]["other_math_modes"].items()}, "| trace", {k: round(v["kernel_only_loop_last_200_avg_us"], 1) for k, v in out.items() if k != "note"})

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session that produces every artefact profiles/README.md lists for a round (run through gpurun):
-# parity suite, headline bench in both arithmetic modes, rocprofv3 kernel stats of the bench command, PMC passes
+# parity suite, headline bench in the three arithmetic modes, rocprofv3 kernel stats of the bench command, PMC passes
 # (HBM traffic, MFMA busy), the secondary timings and the synthetic training iterations.  Outputs: gpurun_out/round/.
 set -o pipefail
 R=$GRAFT_REPO_ROOT
@@ -11,6 +11,7 @@ timeout -k 10 900 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1 |
 tail -1 $O/pytest_gpu.log
 timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err || exit 2
 timeout -k 10 400 python bench.py --math fp32 --no-cpu-baseline > $O/bench_fp32.json 2> $O/bench_fp32.err || exit 3
+timeout -k 10 400 python bench.py --math bf16x3 --no-cpu-baseline > $O/bench_bf16x3.json 2> $O/bench_bf16x3.err || exit 3
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 $R/bench.py --steps 300 --warmup 100 --no-cpu-baseline > $O/prof_bench.log 2>&1 || exit 4
 cd $R
