@@ -11,7 +11,7 @@ open(os.path.join(P, f"{tag}_bench_bf16x3.json"), "w").write(last(os.path.join(R
 shutil.copy(os.path.join(R, "prof", "bench_kernel_stats.csv"), os.path.join(P, f"{tag}_bench_kernel_stats.csv"))
 os.makedirs(os.path.join(P, f"{tag}_pmc"), exist_ok=True)
 for p in ("p1", "p2", "p3", "p4"):
-    shutil.copy(glob.glob(os.path.join(R, "pmc", p, "*", "*_counter_collection.csv"))[0], os.path.join(P, f"{tag}_pmc", f"{p}_counter_collection.csv"))
+    shutil.copy(max(glob.glob(os.path.join(R, "pmc", p, "*", "*_counter_collection.csv")), key=os.path.getmtime), os.path.join(P, f"{tag}_pmc", f"{p}_counter_collection.csv"))
 shutil.copy(os.path.join(R, "secondary.json"), os.path.join(P, f"{tag}_secondary.json"))
 shutil.copy(os.path.join(R, "train_configs.jsonl"), os.path.join(P, f"{tag}_train_configs.jsonl"))
 rows = list(csv.DictReader(open(os.path.join(R, "prof", "bench_kernel_trace.csv"))))

@@ -6,7 +6,7 @@ root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 math = sys.argv[2] if len(sys.argv) > 2 else "bf16x3"      # which arithmetic mode the PMC run profiled (LSNF_MATH)
 KEY = {"bf16x3": "lsnf_fwd3b_kernel", "fp16x2": "lsnf_fwd2h_kernel"}.get(math, "lsnf_fwd_kernel")   # the mode's dominant kernel
 def mean(counter, p):
-    f = glob.glob(os.path.join(root, p, "*", "*_counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(root, p, "*", "*_counter_collection.csv")), key=os.path.getmtime)   # newest (older runs may linger)
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and KEY in r["Kernel_Name"]]
     return sum(v) / len(v)
 fetch_kb, write_kb = mean("FETCH_SIZE", "p3"), mean("WRITE_SIZE", "p4")
