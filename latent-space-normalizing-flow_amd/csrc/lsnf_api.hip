@@ -2,6 +2,7 @@
 // Argument validation happens here, on the host, BEFORE any kernel is launched: operand shapes
 // and alignments are checked against what the kernels and their grids assume.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -24,11 +25,11 @@ hipError_t lsnf_launch_forward(const LsnfGeo& g, const float* plan, int first_bl
 hipError_t lsnf_launch_forward3(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                 const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                 float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
-                                int shape16, unsigned* guard, hipStream_t stream);
+                                int shape16, unsigned* guard, unsigned guard_id, hipStream_t stream);
 hipError_t lsnf_launch_forward2h(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                  const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                  float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
-                                 int shape16, unsigned* guard, hipStream_t stream);
+                                 int shape16, unsigned* guard, unsigned guard_id, hipStream_t stream);
 hipError_t lsnf_launch_small3_forward(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                       const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                       float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
@@ -213,16 +214,19 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
         const bool fp16_ok = math_mode() == LSNF_MATH_FP16X2 && z_in != z_out && (objective == nullptr || objective != logdet_out);
         if (fp16_ok) {                            // two fp16 terms per operand, three MFMAs per product (lsnf_fwd2h.hip) ...
             unsigned* guard = reinterpret_cast<unsigned*>(const_cast<float*>(plan) + g.off_guard);
+            static std::atomic<unsigned> launch_id{0};
+            unsigned id = ++launch_id;
+            if (id == 0) id = ++launch_id;        // 0 means "no fix-up due"
             e = lsnf_launch_forward2h(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
-                                      z_saved, act_saved, stats, vec4, 1, guard, (hipStream_t)stream);
+                                      z_saved, act_saved, stats, vec4, 1, guard, id, (hipStream_t)stream);
             if (e == hipSuccess)                  // ... and the bf16x3 fix-up pass behind it: exits at once unless the fp16
                                                   // kernel met an operand outside fp16's range, else recomputes every row
                 e = lsnf_launch_forward3(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
-                                         z_saved, act_saved, stats, vec4, 1, guard, (hipStream_t)stream);
+                                         z_saved, act_saved, stats, vec4, 1, guard, id, (hipStream_t)stream);
         }
         if (split || (e == hipErrorInvalidValue && math_mode() == LSNF_MATH_FP16X2))   // error-free split on the bf16 matrix pipe (lsnf_fwd3.hip)
             e = lsnf_launch_forward3(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
-                                     z_saved, act_saved, stats, vec4, math_mode() != LSNF_MATH_BF16X3_32, nullptr, (hipStream_t)stream);
+                                     z_saved, act_saved, stats, vec4, math_mode() != LSNF_MATH_BF16X3_32, nullptr, 0u, (hipStream_t)stream);
         if (e == hipErrorInvalidValue)            // fp32 MFMA kernel (also: stacks too deep for fwd3's LDS budget)
             e = lsnf_launch_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
                                     z_saved, act_saved, stats, vec4, (hipStream_t)stream);

@@ -44,8 +44,10 @@ struct Fwd3Args {
     double* stats;
     unsigned long long* stamps;        // LSNF_STAMPS diagnostic build only: [waves & 2047][64] clock stamps
     int shape16;                       // 1: the v_mfma_f32_16x16x32_bf16 variant (panels3 then points at its operand order)
-    unsigned* guard;                   // fp16 range guard (lsnf_layout.h off_guard) or nullptr.  fp16x2 kernel: raises [1];
-                                       // bf16x3 L16 kernel: runs only if [1] is raised (the fix-up pass), then lowers it
+    unsigned* guard;                   // fp16 range guard (lsnf_layout.h off_guard) or nullptr.  fp16x2 kernel: writes its
+    unsigned guard_id;                 // launch id into its slot's flag; bf16x3 L16 kernel: runs only if the flag holds
+                                       // that id (the fix-up pass), then clears it.  Slots are per launch id, so launches
+                                       // of one plan in flight on several streams do not see each other's flags
 };
 
 #ifdef LSNF_STAMPS   // in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz (tools/stamps_fwd3.py)
@@ -346,10 +348,12 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3b_kernel(const Fwd3
     F3_STAMP(0, "s_memtime");
     F3_STAMP(50, "s_memrealtime");
 #if LSNF_L16_PARTS == 3
-    if (a.guard && a.guard[1] == 0u) return;      // fix-up pass of the fp16 forward: nothing overflowed (kernel-uniform)
+    unsigned* const gslot = a.guard ? a.guard + 2 * (1 + a.guard_id % LSNF_GUARD_SLOTS) : nullptr;
+    if (gslot && gslot[0] != a.guard_id) return;  // fix-up pass of the fp16 forward: nothing overflowed (kernel-uniform)
 #else
+    unsigned* const gslot = a.guard + 2 * (1 + a.guard_id % LSNF_GUARD_SLOTS);
     if (a.guard[0] != 0u) {                       // weights outside fp16's range (prepare): leave everything to the fix-up pass
-        if (tid == 0) a.guard[1] = 1u;
+        if (tid == 0) gslot[0] = a.guard_id;
         return;
     }
     // Range guard.  An operand x with |x| >= 65520 splits into x1 = +-inf, x2 = x - x1 = -+inf, and every output of the
@@ -502,12 +506,12 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3b_kernel(const Fwd3
 #if LSNF_L16_PARTS == 3
     if (a.guard) {                                // fix-up pass done: the workgroup drawing the last ticket lowers the flag
         __syncthreads();
-        if (tid == 0 && atomicAdd(&a.guard[2], 1u) == gridDim.x - 1) { atomicExch(&a.guard[1], 0u); atomicExch(&a.guard[2], 0u); }
+        if (tid == 0 && atomicAdd(&gslot[1], 1u) == gridDim.x - 1) { atomicExch(&gslot[0], 0u); atomicExch(&gslot[1], 0u); }
     }
 #else
     // an operand at or beyond fp16's range (NaN compares false: it propagates by itself): results of this launch are
     // not to be trusted -- raise the flag, the bf16x3 fix-up pass queued behind this kernel recomputes every row
-    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) a.guard[1] = 1u;
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) gslot[0] = a.guard_id;
 #endif
     F3_STAMP(41, "s_memtime");
     F3_STAMP(51, "s_memrealtime");
@@ -542,10 +546,10 @@ hipError_t launch_fwd3(const Fwd3Args& a, hipStream_t stream) {
 hipError_t LSNF_FWD3_ENTRY(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                 const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                 float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
-                                int shape16, unsigned* guard, hipStream_t stream) {
+                                int shape16, unsigned* guard, unsigned guard_id, hipStream_t stream) {
     Fwd3Args a;
     a.shape16 = shape16;
-    a.guard = guard;
+    a.guard = guard; a.guard_id = guard_id;
 #if LSNF_L16_PARTS == 3
     if (guard && !shape16) return hipErrorInvalidValue;      // the fix-up pass is the L16 kernel
 #else

@@ -28,7 +28,8 @@
 // i.e. k-slot j of lane-half h in k-step s is accumulator register 8*s + j of that lane-half -- an output tile
 // converted to bf16 pairs in register order is directly the next GEMM's B operand.
 #define LSNF_FRAG3_FLOATS 1536 /* 2 k-steps x 3 parts x 1 KiB, in 4-byte units */
-#define LSNF_GUARD_WORDS 4
+#define LSNF_GUARD_WORDS 256
+#define LSNF_GUARD_SLOTS 127 /* (flag, ticket) pairs after word pair 0 */
 #define LSNF_F16_GUARD_MAX 65504.0f /* |x| >= this does not survive the round-to-nearest fp16 conversion */
 #define LSNF_FRAG2H_FLOATS 1024 /* fp16 two-term split: 2 feature halves x 2 parts x 1 KiB */
 // The same three bf16 matrices once more in the A-operand order of v_mfma_f32_16x16x32_bf16 (lsnf_fwd3.hip, 16x16 variant;
@@ -65,7 +66,8 @@ struct LsnfGeo {
     int f2h_block_floats;       // forward panels as two fp16 matrices (LSNF_MATH_FP16X2), 16x16x32 operand order
     size_t off_f2h_panels;
     size_t off_guard;           // LSNF_GUARD_WORDS 32-bit words of the fp16 range guard (lsnf_fwd2h.hip): [0] weights outside
-                                // fp16's range (set by prepare), [1] an operand overflowed in the last fp16 forward, [2] ticket
+                                // fp16's range (set by prepare); then LSNF_GUARD_SLOTS pairs (flag, ticket): a forward
+                                // launch with id i uses pair 1 + i % SLOTS -- flag = i while its fix-up pass is due
     size_t total_floats;
 };
 

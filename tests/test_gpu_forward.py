@@ -187,6 +187,24 @@ def test_fp16_split_range_guard(lsnf, gpu_device):
         b_small = lsnf.forward(plan, z.to(gpu_device))
         assert not torch.equal(b_small[2], h_small[2])                        # (the two modes do differ in the last bits)
         assert ((b_small[2] - h_small[2]).abs() / b_small[2].abs().clamp_min(1.0)).max().item() <= 2e-6
+        # launches of one plan in flight on two streams keep their flags apart (per-launch guard slots): the overflowing
+        # launch is recomputed, its neighbours on the other stream keep the fp16 kernel's results
+        lsnf.flow.set_math_mode(lsnf.flow.MATH_FP16X2)
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        zb, zs = z_big.to(gpu_device), z.to(gpu_device)
+        torch.cuda.synchronize()
+        outs_big, outs_small = [], []
+        for _ in range(6):
+            with torch.cuda.stream(s1):
+                outs_big.append(lsnf.forward(plan, zb))
+            with torch.cuda.stream(s2):
+                outs_small.append(lsnf.forward(plan, zs))
+        torch.cuda.synchronize()
+        for o in outs_big:
+            assert torch.equal(o[2], ref_big[2]) and torch.equal(o[0], ref_big[0])
+        for o in outs_small:
+            assert torch.equal(o[2], h_small[2]) and torch.equal(o[0], h_small[0])
+        lsnf.flow.set_math_mode(lsnf.flow.MATH_BF16X3)
         # folded weights outside fp16's range (actnorm logs = 5 -> exp(15)): prepare marks the plan, every launch is recomputed
         q = dict(p)
         k = O.block_prefix(2) + "actnorm.logs"
