@@ -105,8 +105,9 @@ def main():
                     help="arithmetic of the forward's GEMMs: fp16x2 = two-term fp16 split, three fp16 MFMAs per product, "
                          "range-guarded by a bf16x3 fix-up pass (fp32-class accuracy, the library default); bf16x3 = "
                          "error-free three-way bf16 split, six bf16 MFMAs per product; fp32 = fp32 MFMA")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="HIP streams the independent steps alternate over (2: the head of step i+1 overlaps the tail of step i)")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="HIP streams the independent steps rotate over (the load head of step i+1 and the early-exit fix-up "
+                         "launch of step i overlap the store tail of step i; measured 1: 75.8, 2: 70.3, 3: 60.7, 4: 64.7, 6: 61.1 us/step)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -136,7 +137,8 @@ def main():
 
     # Steps are independent batches (synthetic z), so consecutive steps alternate over `--streams` HIP streams, each
     # with its own output buffers: while the last workgroups of step i drain their stores, the workgroups of step
-    # i+1 already load their rows on the CUs that have become free (measured 174 -> 164 us per step).  Every step is
+    # i+1 already load their rows on the CUs that have become free (fp32 generation: 174 -> 164 us per step; today's
+    # fp16x2 forward, whose every launch is followed by an early-exit fix-up launch: 70.3 us at 2 streams, 60.7 at 3).  Every step is
     # still a complete forward over 65 536 rows; K steps are timed, as the contract says.
     n_streams = max(1, args.streams)
     main_stream = torch.cuda.current_stream()

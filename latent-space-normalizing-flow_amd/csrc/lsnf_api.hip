@@ -47,7 +47,9 @@ hipError_t lsnf_launch_backward_z(const LsnfGeo& g, const float* plan, int B, co
 hipError_t lsnf_launch_small3_reverse(const LsnfGeo& g, const float* plan, int B, const float* z_in, const float* objective,
                                       float* z_out, float* objective_out, int vec4, hipStream_t stream);
 hipError_t lsnf_launch_reverse3(const LsnfGeo& g, const float* plan, int B, const float* z_in, const float* objective,
-                                float* z_out, float* objective_out, int vec4, hipStream_t stream);
+                                float* z_out, float* objective_out, int vec4, unsigned* guard, unsigned guard_id, hipStream_t stream);
+hipError_t lsnf_launch_reverse2h(const LsnfGeo& g, const float* plan, int B, const float* z_in, const float* objective,
+                                 float* z_out, float* objective_out, int vec4, unsigned* guard, unsigned guard_id, hipStream_t stream);
 hipError_t lsnf_launch_small_reverse(const LsnfGeo& g, const float* plan, int B, const float* z_in, const float* objective,
                                      float* z_out, float* objective_out, int vec4, hipStream_t stream);
 hipError_t lsnf_launch_small_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
@@ -109,6 +111,13 @@ int math_mode() {
     return g_math;
 }
 // modes whose latency / backward / reverse kernels are the bf16x3 "L16" ones (LSNF_MATH_FP16X2 changes the throughput forward only)
+// ids of the range-guarded fp16 launches (slot and flag value of their fix-up pass); 0 means "no fix-up due"
+unsigned next_launch_id() {
+    static std::atomic<unsigned> launch_id{0};
+    unsigned id = ++launch_id;
+    if (id == 0) id = ++launch_id;
+    return id;
+}
 bool l16_math() { return math_mode() == LSNF_MATH_BF16X3 || math_mode() == LSNF_MATH_FP16X2; }
 
 int geo_or_fail(LsnfGeo* g, int nz, int width, int depth, int coupling) {
@@ -214,9 +223,7 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
         const bool fp16_ok = math_mode() == LSNF_MATH_FP16X2 && z_in != z_out && (objective == nullptr || objective != logdet_out);
         if (fp16_ok) {                            // two fp16 terms per operand, three MFMAs per product (lsnf_fwd2h.hip) ...
             unsigned* guard = reinterpret_cast<unsigned*>(const_cast<float*>(plan) + g.off_guard);
-            static std::atomic<unsigned> launch_id{0};
-            unsigned id = ++launch_id;
-            if (id == 0) id = ++launch_id;        // 0 means "no fix-up due"
+            const unsigned id = next_launch_id();
             e = lsnf_launch_forward2h(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
                                       z_saved, act_saved, stats, vec4, 1, guard, id, (hipStream_t)stream);
             if (e == hipSuccess)                  // ... and the bf16x3 fix-up pass behind it: exits at once unless the fp16
@@ -255,8 +262,16 @@ int lsnf_reverse(const float* plan, int nz, int width, int depth, int coupling, 
     const int vec4 = row_vector_width(g, {z_in, z_out});
     hipError_t e = hipErrorInvalidValue;
     if (l16_math()) {        // on the bf16 pipe: lsnf_small3_rev.hip / lsnf_rev3.hip
-        if (B > small_batch_max())
-            e = lsnf_launch_reverse3(g, plan, B, z_in, objective, z_out, objective_out, vec4, (hipStream_t)stream);
+        // fp16 two-term split (lsnf_rev2h.hip) + the bf16x3 kernel behind it as the early-exit fix-up pass, as in lsnf_forward
+        if (B > small_batch_max() && math_mode() == LSNF_MATH_FP16X2 && z_in != z_out && (objective == nullptr || objective != objective_out)) {
+            unsigned* guard = reinterpret_cast<unsigned*>(const_cast<float*>(plan) + g.off_guard);
+            const unsigned id = next_launch_id();
+            e = lsnf_launch_reverse2h(g, plan, B, z_in, objective, z_out, objective_out, vec4, guard, id, (hipStream_t)stream);
+            if (e == hipSuccess)
+                e = lsnf_launch_reverse3(g, plan, B, z_in, objective, z_out, objective_out, vec4, guard, id, (hipStream_t)stream);
+        }
+        if (B > small_batch_max() && e == hipErrorInvalidValue)
+            e = lsnf_launch_reverse3(g, plan, B, z_in, objective, z_out, objective_out, vec4, nullptr, 0u, (hipStream_t)stream);
         // (the latency form is also faster than the fp32 throughput reverse where the bf16 throughput form does not fit)
         if (e == hipErrorInvalidValue && small_batch_max() > 0)
             e = lsnf_launch_small3_reverse(g, plan, B, z_in, objective, z_out, objective_out, vec4, (hipStream_t)stream);

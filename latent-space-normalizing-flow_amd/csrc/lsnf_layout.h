@@ -65,6 +65,8 @@ struct LsnfGeo {
     size_t off_i3b_panels;
     int f2h_block_floats;       // forward panels as two fp16 matrices (LSNF_MATH_FP16X2), 16x16x32 operand order
     size_t off_f2h_panels;
+    int i2h_block_floats;       // inverse panel I1 likewise (lsnf_rev2h.hip)
+    size_t off_i2h_panels;
     size_t off_guard;           // LSNF_GUARD_WORDS 32-bit words of the fp16 range guard (lsnf_fwd2h.hip): [0] weights outside
                                 // fp16's range (set by prepare); then LSNF_GUARD_SLOTS pairs (flag, ticket): a forward
                                 // launch with id i uses pair 1 + i % SLOTS -- flag = i while its fix-up pass is due
@@ -152,6 +154,9 @@ static inline int lsnf_geo_init(LsnfGeo* g, int nz, int width, int depth, int co
     o = (o + 255) & ~(size_t)255;
     g->f2h_block_floats = LSNF_FRAG2H_FLOATS * (NZT * NZT + WT * HT + WT * WT + 2 * HT * WT);
     g->off_f2h_panels = o; o += (size_t)depth * g->f2h_block_floats;
+    o = (o + 255) & ~(size_t)255;
+    g->i2h_block_floats = LSNF_FRAG2H_FLOATS * (NZT * NZT);
+    g->off_i2h_panels = o; o += (size_t)depth * g->i2h_block_floats;
     o = (o + 255) & ~(size_t)255;
     g->off_guard = o; o += 256;
     g->total_floats = o;

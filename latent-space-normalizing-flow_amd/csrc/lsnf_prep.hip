@@ -436,6 +436,22 @@ __global__ __launch_bounds__(256) void lsnf_pack_kernel(LsnfParamPtrs pp, LsnfGe
             reinterpret_cast<unsigned*>(plan + g.off_guard)[0] = 1u;                                  // fp16 forward unusable: lsnf_fwd2h.hip defers to bf16x3
         dst[q] = f16_part_bits(w0, part) | (f16_part_bits(w1, part) << 16);
     }
+    // ---- fp16 two-term inverse panel I1 (lsnf_rev2h.hip): Winv' = Winv diag(exp(-3 logs_a)), 16x16x32 operand order
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < g.i2h_block_floats; q += gridDim.x * 256) {
+        unsigned* dst = reinterpret_cast<unsigned*>(plan + g.off_i2h_panels + (size_t)blk * g.i2h_block_floats);
+        int k0, k1, n, part;
+        frag2h_decode(q, NZT, &k0, &k1, &n, &part);
+        const SplitIdx sn = split_nat(n, HT, g.half);
+        double v[2] = {0.0, 0.0};
+        const int ks[2] = {k0, k1};
+        for (int i = 0; i < 2; ++i) {
+            const SplitIdx sk = split_nat(ks[i], HT, g.half);
+            if (sk.ok && sn.ok) v[i] = sb[(size_t)sk.nat * nz + sn.nat] * exp(-(double)(P[P_ALOGS][sn.nat] * 3.0f));
+        }
+        if (!(fabs(v[0]) < (double)LSNF_F16_GUARD_MAX) || !(fabs(v[1]) < (double)LSNF_F16_GUARD_MAX))
+            reinterpret_cast<unsigned*>(plan + g.off_guard)[0] = 1u;
+        dst[q] = f16_part_bits(v[0], part) | (f16_part_bits(v[1], part) << 16);
+    }
 }
 
 size_t lsnf_prep_scratch_bytes(int nz, int depth) { return sizeof(double) * scratch_block_doubles(nz) * (size_t)depth; }

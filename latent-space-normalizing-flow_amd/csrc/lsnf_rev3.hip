@@ -11,7 +11,7 @@ namespace {
 template <int HT_, int WT_>
 struct Rev3Cfg : LsnfStackCfg<HT_, WT_> {
     using S = LsnfStackCfg<HT_, WT_>;
-    static constexpr int F = LSNF_FRAG3_FLOATS;
+    static constexpr int F = L16_FRAG_FLOATS;
     static constexpr int OFF3_S2 = F * S::P1 * S::KT1;
     static constexpr int OFF3_S3 = OFF3_S2 + F * S::P2 * S::KT2;
     static constexpr int OFF3_S4 = OFF3_S3 + F * S::P3 * S::KT3;
@@ -25,6 +25,7 @@ struct Rev3Args {
     const float* fwd_consts; const float* inv_consts; const float* panels3b; const float* ipanels3b;
     const float* z_in; const float* objective; float* z_out; float* objective_out;
     int B, nz, half, depth, vec4;
+    unsigned* guard; unsigned guard_id;      // fp16 range guard, as in lsnf_fwd3.hip (Fwd3Args)
 };
 
 template <class C, int NW>
@@ -37,6 +38,17 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_rev3_kernel(const Rev3Args a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int vec4 = a.vec4;
+#if LSNF_L16_PARTS == 3
+    unsigned* const gslot = a.guard ? a.guard + 2 * (1 + a.guard_id % LSNF_GUARD_SLOTS) : nullptr;
+    if (gslot && gslot[0] != a.guard_id) return;  // fix-up pass of the fp16 reverse: nothing overflowed (kernel-uniform)
+#else
+    unsigned* const gslot = a.guard + 2 * (1 + a.guard_id % LSNF_GUARD_SLOTS);
+    if (a.guard[0] != 0u) {                       // weights outside fp16's range (prepare): leave everything to the fix-up pass
+        if (tid == 0) gslot[0] = a.guard_id;
+        return;
+    }
+    bool bad = false;                             // an operand beyond fp16's range turns every output of its GEMM into NaN
+#endif
 
     const int last = a.depth - 1;
     Pipe3<NW> pipe;
@@ -58,8 +70,13 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_rev3_kernel(const Rev3Args a)
     float obj[2];
 #pragma unroll
     for (int st = 0; st < 2; ++st) obj[st] = a.objective ? a.objective[rows[st]] : 0.0f;
+#if LSNF_L16_PARTS == 3
     auto keep = [](f32x16 acc, int) { return acc; };
     auto relu = [](f32x16 acc, int) { return lsnf_relu16(acc); };
+#else
+    auto keep = [&](f32x16 acc, int t) { if (t == 0) bad = bad || acc[0] != acc[0] || acc[4] != acc[4]; return acc; };
+    auto relu = [&](f32x16 acc, int t) { if (t == 0) bad = bad || acc[0] != acc[0] || acc[4] != acc[4]; return lsnf_relu16(acc); };
+#endif
 
     for (int blk = last; blk >= 0; --blk) {
         const float* cb = cst + blk * C::CONST_PER_BLOCK;
@@ -129,6 +146,14 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_rev3_kernel(const Rev3Args a)
         for (int st = 0; st < 2; ++st)
             if (live[st] && g == 0) a.objective_out[sample[st]] = obj[st];
     }
+#if LSNF_L16_PARTS == 3
+    if (gslot) {                                  // fix-up pass done: the workgroup drawing the last ticket clears the slot
+        __syncthreads();
+        if (tid == 0 && atomicAdd(&gslot[1], 1u) == gridDim.x - 1) { atomicExch(&gslot[0], 0u); atomicExch(&gslot[1], 0u); }
+    }
+#else
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) gslot[0] = a.guard_id;
+#endif
 }
 
 template <class C, int NW>
@@ -149,11 +174,20 @@ hipError_t launch_rev3(const Rev3Args& a, hipStream_t stream) {
 }  // namespace
 
 // host-side dispatcher (called from lsnf_api.hip); hipErrorInvalidValue = not covered (e.g. very deep stacks: LDS)
-hipError_t lsnf_launch_reverse3(const LsnfGeo& g, const float* plan, int B, const float* z_in, const float* objective,
-                                float* z_out, float* objective_out, int vec4, hipStream_t stream) {
+#ifndef LSNF_REV3_ENTRY
+#define LSNF_REV3_ENTRY lsnf_launch_reverse3
+#endif
+hipError_t LSNF_REV3_ENTRY(const LsnfGeo& g, const float* plan, int B, const float* z_in, const float* objective,
+                           float* z_out, float* objective_out, int vec4, unsigned* guard, unsigned guard_id, hipStream_t stream) {
     Rev3Args a;
+    a.guard = guard; a.guard_id = guard_id;
     a.fwd_consts = plan + g.off_fwd_const; a.inv_consts = plan + g.off_inv_const;
+#if LSNF_L16_PARTS == 3
     a.panels3b = plan + g.off_f3b_panels; a.ipanels3b = plan + g.off_i3b_panels;
+#else
+    if (!guard) return hipErrorInvalidValue;
+    a.panels3b = plan + g.off_f2h_panels; a.ipanels3b = plan + g.off_i2h_panels;
+#endif
     a.z_in = z_in; a.objective = objective; a.z_out = z_out; a.objective_out = objective_out;
     a.B = B; a.nz = g.nz; a.half = g.half; a.depth = g.depth; a.vec4 = vec4;
     if (g.HT == 1 && g.WT == 1) return launch_rev3<Rev3Cfg<1, 1>>(a, stream);

@@ -198,3 +198,42 @@ def test_default_dispatch_large_batch(lsnf, gpu_device):
     zn, ll2, _, _ = lsnf.langevin_step(plan, z.to(gpu_device), None, None, 0.1)
     zr = z[idx].double() - 0.005 * ref.double()
     assert ((zn.cpu()[idx].double() - zr)[ok].abs().max() / zr.abs().max()).item() <= 2e-5
+
+
+def test_fp16_split_range_guard_reverse(lsnf, gpu_device):
+    """The throughput reverse on the two-term fp16 split (lsnf_rev2h.hip) under the same range guard as the forward: a
+    row beyond fp16's range makes the bf16x3 pass behind it recompute the launch (bit-equal to LSNF_MATH_BF16X3), ordinary
+    launches keep the fp16 kernel's results, and those match the oracle."""
+    nz, width, depth, B = 128, 64, 5, 33000
+    p = O.init_params(nz, width, depth, seed=31)
+    plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
+    g = torch.Generator().manual_seed(32)
+    z = torch.randn(B, nz, generator=g)
+    z_big = z.clone()
+    z_big[777] *= 5.0e4
+    obj = torch.randn(B, generator=g)
+    prev_small = lsnf.flow.set_small_batch_max(0)
+    prev = lsnf.flow.set_math_mode(lsnf.flow.MATH_BF16X3)
+    try:
+        ref_big = lsnf.reverse(plan, z_big.to(gpu_device), obj.to(gpu_device))
+        ref = lsnf.reverse(plan, z.to(gpu_device), obj.to(gpu_device))
+        lsnf.flow.set_math_mode(lsnf.flow.MATH_FP16X2)
+        got = lsnf.reverse(plan, z.to(gpu_device), obj.to(gpu_device))
+        got_big = lsnf.reverse(plan, z_big.to(gpu_device), obj.to(gpu_device))
+        got2 = lsnf.reverse(plan, z.to(gpu_device), obj.to(gpu_device))
+        # (the huge row itself may legitimately overflow fp32 in the reverse direction -- z2 / sigmoid(p) with p << 0 --
+        # so compare bit patterns: whatever LSNF_MATH_BF16X3 returns, the guarded fp16 mode returns the same)
+        bits = lambda t: t.view(torch.int32)
+        assert torch.equal(bits(got_big[0]), bits(ref_big[0])) and torch.equal(bits(got_big[1]), bits(ref_big[1]))
+        keep = torch.ones(B, dtype=torch.bool, device=gpu_device); keep[777] = False
+        assert torch.isfinite(got_big[0][keep]).all() and torch.isfinite(got_big[1][keep]).all()
+        assert torch.equal(got[0], got2[0]) and torch.equal(got[1], got2[1])
+        assert not torch.equal(got[0], ref[0])                                   # the fp16 kernel did run
+        assert (got[0] - ref[0]).abs().max().item() <= 2e-5 * ref[0].abs().max().item()
+        idx = torch.arange(0, B, 97)
+        xr, negobj = O.flow_reverse(O.to_dtype(p, torch.float64), z[idx].double(), obj[idx].double())
+        assert (got[0].cpu()[idx].double() - xr).abs().max().item() <= 5e-5 * xr.abs().max().item()
+        assert ((got[1].cpu()[idx].double() + negobj).abs() / negobj.abs().clamp_min(1.0)).max().item() <= 1e-5
+    finally:
+        lsnf.flow.set_math_mode(prev)
+        lsnf.flow.set_small_batch_max(prev_small)
