@@ -74,14 +74,14 @@ int lsnf_set_small_batch_max(int rows);
  *                      not bit for bit.
  *   LSNF_MATH_BF16X3_32 : the same scheme on v_mfma_f32_32x32x16_bf16 in the throughput forward (kept for comparison:
  *                      that shape sustains a lower clock on real data, ~8 % slower); latency forward as LSNF_MATH_FP32.
- *   LSNF_MATH_FP16X2 : (default) throughput forward with both operands split into TWO fp16 terms, three fp16 MFMAs
+ *   LSNF_MATH_FP16X2 : (default) throughput forward and reverse with both operands split into TWO fp16 terms, three fp16 MFMAs
  *                      per product (csrc/lsnf_fwd2h.hip; dropped terms <= 2^-22 |w||x|: below the accumulated fp32
  *                      rounding of the dot products, log-prob error vs float64 as LSNF_MATH_FP32); half the matrix work
  *                      of LSNF_MATH_BF16X3.  fp16's range is guarded: a launch in which an operand (or a folded weight)
  *                      reaches 65504 is recomputed by the LSNF_MATH_BF16X3 kernel queued behind it (an early-exit
  *                      launch otherwise), so results are finite wherever the fp32 computation's are; in-place calls
- *                      (z_out == z_in) use LSNF_MATH_BF16X3 directly.  Every other kernel (latency forward, backward,
- *                      reverse) as LSNF_MATH_BF16X3.
+ *                      (z_out == z_in) use LSNF_MATH_BF16X3 directly.  Every other kernel (latency kernels, backward)
+ *                      as LSNF_MATH_BF16X3.
  * mode < 0 only queries.  Returns the previous mode (default LSNF_MATH_DEFAULT, or the LSNF_MATH environment
  * variable "fp32" / "bf16x3" / "bf16x3_32" / "fp16x2"). */
 #define LSNF_MATH_FP32 0
