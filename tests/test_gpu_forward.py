@@ -205,6 +205,22 @@ def test_fp16_split_range_guard(lsnf, gpu_device):
         for o in outs_small:
             assert torch.equal(o[2], h_small[2]) and torch.equal(o[0], h_small[0])
         lsnf.flow.set_math_mode(lsnf.flow.MATH_BF16X3)
+        # an activation that leaves the range in mid-stack (block 0 scales by exp(6), |v| ~ 1e5 from |z| ~ 300) with
+        # every weight and every input inside it: caught at the stage that consumes it
+        q = dict(p)
+        k = O.block_prefix(0) + "actnorm.logs"
+        q[k] = torch.full_like(q[k], 2.0)
+        plan_mid = lsnf.prepare(lsnf.params_from_state_dict(q, depth, gpu_device), nz, width, depth)
+        z_mid = z.clone()
+        z_mid[4321] *= 100.0
+        ref_mid = lsnf.forward(plan_mid, z_mid.to(gpu_device))
+        lsnf.flow.set_math_mode(lsnf.flow.MATH_FP16X2)
+        got_mid = lsnf.forward(plan_mid, z_mid.to(gpu_device))
+        for a, b in zip(ref_mid[:3], got_mid[:3]):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        keep_rows = torch.ones(B, dtype=torch.bool, device=gpu_device); keep_rows[4321] = False
+        assert torch.isfinite(got_mid[2][keep_rows]).all()
+        lsnf.flow.set_math_mode(lsnf.flow.MATH_BF16X3)
         # folded weights outside fp16's range (actnorm logs = 5 -> exp(15)): prepare marks the plan, every launch is recomputed
         q = dict(p)
         k = O.block_prefix(2) + "actnorm.logs"
