@@ -62,6 +62,8 @@ const char* lsnf_last_error(void);
 /* Tuning knob: batches of at most `rows` rows run on the small-batch (latency) kernels, larger ones on the
  * throughput kernels; both compute the same function (results agree to fp32 rounding, not bit for bit).
  * rows < 0 only queries.  Returns the previous value (default 16384, or the LSNF_SMALL_MAX environment variable).
+ * While the threshold is the built-in default, lsnf_forward in LSNF_MATH_FP16X2 switches at 12288 rows already (its
+ * fp16 throughput kernel is the faster one from there); a threshold set here or by LSNF_SMALL_MAX applies as given.
  */
 int lsnf_set_small_batch_max(int rows);
 

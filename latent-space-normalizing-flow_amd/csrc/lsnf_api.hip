@@ -95,8 +95,9 @@ bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0
 
 // rows at or below which the small-batch kernels are used (LSNF_SMALL_MAX overrides; 0 disables them)
 int g_small_max = -1;
+bool g_small_max_set = false;      // threshold chosen by the caller (lsnf_set_small_batch_max / LSNF_SMALL_MAX)
 int small_batch_max() {
-    if (g_small_max < 0) { const char* e = getenv("LSNF_SMALL_MAX"); g_small_max = e ? atoi(e) : LSNF_SMALL_MAX_DEFAULT; }
+    if (g_small_max < 0) { const char* e = getenv("LSNF_SMALL_MAX"); g_small_max = e ? atoi(e) : LSNF_SMALL_MAX_DEFAULT; g_small_max_set = e != nullptr; }
     return g_small_max;
 }
 
@@ -135,7 +136,7 @@ int lsnf_abi_version(void) { return LSNF_ABI_VERSION; }
 
 int lsnf_set_small_batch_max(int rows) {
     const int prev = small_batch_max();
-    if (rows >= 0) g_small_max = rows;
+    if (rows >= 0) { g_small_max = rows; g_small_max_set = true; }
     return prev;
 }
 int lsnf_set_math_mode(int mode) {
@@ -208,7 +209,10 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
     // crossover, throughput kernel (128 rows per workgroup, weights shared through LDS) above it
     hipError_t e;
     const bool split = math_mode() == LSNF_MATH_BF16X3 || math_mode() == LSNF_MATH_BF16X3_32;
-    const int fwd_small_max = small_batch_max();
+    // the fp16x2 throughput forward is the faster one from ~12 K rows (profiles/r01_i_crossover.txt: 40.8 vs 41.9 us at
+    // 12 288, 42.5 vs 51.6 at 16 384) -- used unless the caller has chosen the threshold
+    int fwd_small_max = small_batch_max();
+    if (math_mode() == LSNF_MATH_FP16X2 && !g_small_max_set && fwd_small_max > 12288) fwd_small_max = 12288;
     if (B <= fwd_small_max) {
         e = hipErrorInvalidValue;
         if (l16_math())                           // latency forward on the bf16 pipe: 16-sample workgroups (lsnf_small3_fwd.hip)
