@@ -101,7 +101,10 @@ int lsnf_device_arch(int device, char* buf, size_t buflen);
  * Batch-independent work of one `_netF` evaluation, hoisted out of the per-call path:
  * exp(3*logs) folding of the three actnorms (model.py:264-268), de-interleave of fc_zeros'
  * shift / scale columns (model.py:411-413), log|det W| in float64 (model.py:182), W^-1
- * (model.py:193), all re-laid-out in MFMA-fragment order.  Valid until a parameter changes. */
+ * (model.py:193), all re-laid-out in MFMA-fragment order.  Valid until a parameter changes.
+ * The buffer ends with 1 KiB of guard words that lsnf_forward / lsnf_reverse WRITE in LSNF_MATH_FP16X2 (range-guard
+ * flags of the launches in flight, see lsnf_set_math_mode; hence `const float* plan` there means "weights not modified"):
+ * keep the plan in ordinary read-write device memory and do not share one plan buffer between devices. */
 
 /* Size in floats of the prepared-weight buffer for this geometry (0 on bad geometry). */
 size_t lsnf_plan_floats(int nz, int width, int depth, int coupling);
