@@ -258,6 +258,18 @@ def main():
                 traffic = (json.load(open(tfile)).get(args.math) or {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # the committed rocprofv3 kernel-trace average of the same kernel in the same command (profiles/, newest round),
+        # next to the live HIP-event figure above
+        trace_us = None
+        try:
+            import glob
+            tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_only_from_trace.json")))[-1]
+            ent = json.load(open(tf)).get(rl["kernel"])
+            if ent:
+                trace_us = {"file": os.path.basename(tf), "avg_us": ent["kernel_only_loop_last_200_avg_us"]}
+        except Exception:
+            trace_us = None
+        rl["rocprofv3_kernel_trace"] = trace_us
         line = {
             "metric": "latent-samples/sec through flow+logdet, nz=128 B=65536",
             "value": value, "unit": "latent-samples/s", "n_gpus": world, "steps": args.steps,
