@@ -237,7 +237,7 @@ def main():
                           "the fp32 MFMA peak would be 157.3.  kernel_ms is measured around the launch PAIR the mode issues "
                           "(the fp16 kernel and the bf16x3 fix-up pass behind it, which exits at once unless an operand left "
                           "fp16's range: ~2 us).  The matrix pipe is busy about half of the kernel: the rest is the operand "
-                          "split (2.5 VALU per element), the coupling epilogue and the z rows in / out, none of which "
+                          "split (2 VALU per element), the coupling epilogue and the z rows in / out, none of which "
                           "overlap MFMA issue on a SIMD (DESIGN.md section 5)"}
         elif args.math == "bf16x3":   # the matrix pipe executes 6 bf16 MFMA flops per algorithmic flop: price THAT against the bf16 peak
             rl = {"bound": "mfma", "achieved": SPLIT_MFMA_PER_PRODUCT * tflops, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",

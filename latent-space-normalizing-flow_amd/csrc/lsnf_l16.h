@@ -162,7 +162,13 @@ __device__ __forceinline__ void l16_split_tile(const f32x16& x, Split3& s0, Spli
             w[st][0][q] = p1; w[st][1][q] = p2; w[st][2][q] = pk_bf16(a, c);
 #else
             const f16x2 h1 = pk_f16(a, c);
-            a -= (float)h1[0]; c -= (float)h1[1];
+            {   // residuals a - x1.lo, c - x1.hi in one v_fma_mix_f32 each (f16 operand read in place: no v_cvt_f32_f16)
+                const unsigned hp = __builtin_bit_cast(unsigned, h1);
+                float ra, rc;
+                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hp), "v"(a));
+                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rc) : "v"(hp), "v"(c));
+                a = ra; c = rc;
+            }
             w[st][0][q] = __builtin_bit_cast(unsigned, h1); w[st][1][q] = __builtin_bit_cast(unsigned, pk_f16(a, c));
 #endif
         }
