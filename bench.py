@@ -1,23 +1,37 @@
 #!/usr/bin/env python3
-"""Headline benchmark: latent-samples/sec through flow + log-det (+ log-prob), CIFAR-10 flow
-geometry nz=128 f_width=64 f_depth=5, B=65536 rows PER GPU of synthetic z (BASELINE.json configs[2]).
+"""Headline benchmark: latent-samples/sec through flow + log-det (+ log-prob), CIFAR-10 flow geometry
+nz=128 f_width=64 f_depth=5, B=65536 rows of synthetic z per evaluation (BASELINE.json configs[2]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]            # N > 1 without torchrun: starts its own N ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the hot path over one batch: the fused forward launch (z -> z1, logdet, ll, and
-sum_b ll accumulated in the kernel's epilogue, train.py:320) and -- for N > 1 -- the single RCCL all-reduce
-of that sum (asynchronous).  Steps are independent batches and alternate over two HIP streams (--streams).
-z, the prepared weights and all outputs are resident in HBM when the timed region starts.
-Prints ONE JSON line on rank 0 (contract in the task statement), including
-  "roofline":     the forward kernel's algorithmic FLOP/s (HIP-event timed, kernel-only loop) against
-                  the dense fp32 MFMA peak of MI355X,
-  "cpu_baseline": the oracle (PyTorch-CPU restatement of the reference) timed on this box's host
-                  cores on a bounded sample of the same workload (rank 0, N = 1 only).
+A step = one pass of the hot path over one batch: the fused forward launch (z -> z1, logdet, ll, and sum_b ll
+accumulated in the kernel's epilogue, train.py:320) and -- for N > 1 -- the single RCCL all-reduce of that sum,
+one per evaluation (asynchronous).  Steps are independent batches and rotate over `--streams` HIP streams; the
+single-stream figure is reported beside it.  z, the prepared weights and all outputs are resident in HBM when the
+timed region starts.
+
+Arithmetic of the headline (`--math`, default bf16x3): every GEMM operand is split error-free into three bf16 terms
+(24 significand bits, fp32's exponent range), six bf16 MFMAs per product, fp32 accumulation -- not narrower than the
+reference's fp32 matmuls (model.py:187,326,347).  `--math fp32` runs the fp32-MFMA kernels; `--math fp16x2` (two fp16
+terms, 22 bits) is an opt-in mode and never the headline.
+
+N > 1: the headline is STRONG scaling -- the 65 536 rows of one evaluation sharded contiguously
+over the ranks (`parallel.shard_bounds`), one all-reduce per evaluation -- and the same run also times WEAK scaling
+(65 536 rows per GPU, `--weak-bucket` evaluations per collective) and reports it as `weak_scaling`.
+
+Prints ONE JSON line on rank 0, including
+  "roofline":     the forward kernel's ALGORITHMIC FLOP/s (327 680 FLOP/sample x rows / HIP-event time of a
+                  single-stream kernel-only loop, measured in this run) against the dense peak of the matrix pipe it
+                  runs on, plus the same rate against the fp32-MFMA peak and the executed-flops pipe utilisation;
+  "cpu_baseline": the oracle (PyTorch-CPU restatement of the reference) timed on this box's host cores on a bounded
+                  sample of the same workload (rank 0, N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,13 +42,30 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 NZ, WIDTH, DEPTH = 128, 64, 5
-B_PER_GPU = 65536
+B_GLOBAL = 65536
 FLOP_PER_SAMPLE = DEPTH * (2 * NZ * NZ + 2 * (NZ // 2 * WIDTH + WIDTH * WIDTH + WIDTH * NZ))  # 327 680
 BYTES_PER_SAMPLE_FUSED = 8 * NZ + 8                                                            # 1 032 (whole stack fused)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
-PEAK_BF16_MFMA_TFLOPS = 2516.6  # MI355X_MICROARCH.md: "~2.5 PF dense" = 16 x the fp32 matrix rate (same table)
-SPLIT_MFMA_PER_PRODUCT = 6      # bf16x3 mode: six bf16 MFMAs of K=16 carry one fp32-accurate 32x32x16 product
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # MI355X_MICROARCH.md: "~2.5 PF dense" = 16 x the fp32 matrix rate (same table); fp16 = bf16
 PEAK_HBM_GBS = 8000.0
+# executed MFMA flops per algorithmic flop, pipe peak, kernel of the mode (B = 65 536 instantiation)
+MODES = {
+    "bf16x3": dict(exec_per_alg=6, peak=PEAK_BF16_MFMA_TFLOPS, pipe="bf16 MFMA", dtype="bf16x3",
+                   kernel="lsnf_fwd3b_kernel<Fwd3Cfg<2,2>, 8>"),
+    "fp32": dict(exec_per_alg=1, peak=PEAK_FP32_MFMA_TFLOPS, pipe="fp32 MFMA", dtype="f32",
+                 kernel="lsnf_fwd_kernel<FwdCfg<2,2>, 8>"),
+    "fp16x2": dict(exec_per_alg=3, peak=PEAK_BF16_MFMA_TFLOPS, pipe="fp16 MFMA", dtype="fp16x2",
+                   kernel="lsnf_fwd2h_kernel<Fwd3Cfg<2,2>, 8>"),
+}
+MATH_TEXT = {
+    "bf16x3": "bf16x3: every GEMM operand split error-free into three bf16 terms (3 x 8 = 24 significand bits, fp32's "
+              "exponent range), six bf16 MFMAs (16x16x32) per product, fp32 accumulation; dropped terms <= 2^-26|w||x|; "
+              "log-prob error vs float64 equals the fp32-MFMA kernel's (tests/test_gpu_forward.py::"
+              "test_split_bf16_is_fp32_faithful)",
+    "fp32": "fp32 MFMA (v_mfma_f32_32x32x2_f32), bit-for-bit an fmaf chain",
+    "fp16x2": "fp16x2 (opt-in, narrower than the reference's fp32: 11+11 operand bits): two fp16 terms per operand, three "
+              "fp16 MFMAs per product, range-guarded by a bf16x3 fix-up pass",
+}
 
 
 def synth_weights(seed=1):
@@ -65,7 +96,7 @@ def cpu_baseline(weights, budget_s=14.0):
         for j, k in enumerate(keys):
             t = weights[i * 12 + j]
             p[O.block_prefix(i) + k] = t.reshape(1, -1) if t.dim() == 1 else t
-    z = torch.randn(B_PER_GPU, NZ, generator=torch.Generator().manual_seed(1234))
+    z = torch.randn(B_GLOBAL, NZ, generator=torch.Generator().manual_seed(1234))
     all_threads = torch.get_num_threads()
     cands = sorted({c for c in (8, 16, 32, 64, all_threads) if c <= all_threads})
     t_start = time.perf_counter()
@@ -87,34 +118,98 @@ def cpu_baseline(weights, budget_s=14.0):
     torch.set_num_threads(all_threads)
     times.sort()
     med = times[len(times) // 2]
-    return {"value": B_PER_GPU / med, "unit": "latent-samples/s", "cores": best, "kind": "port",
-            "sample": f"{len(times)} full-size calls (B={B_PER_GPU}, nz={NZ}) of oracle.flow_log_prob, torch-CPU fp32 "
+    return {"value": B_GLOBAL / med, "unit": "latent-samples/s", "cores": best, "kind": "port",
+            "sample": f"{len(times)} full-size calls (B={B_GLOBAL}, nz={NZ}) of oracle.flow_log_prob, torch-CPU fp32 "
                       f"no_grad, median {med * 1e3:.1f} ms at {best} threads (probe ms/call: "
                       + ", ".join(f"{c}t={probe[c] * 1e3:.0f}" for c in cands) + f"; host has {all_threads} threads)"}
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` started without torch.distributed.run: start N fresh child ranks (one per GPU) BEFORE this
+    process has made any GPU call, pass their output through and return the launcher's exit code.  The parent never
+    touches the GPU (and never exec()s: it stays the parent of the ranks)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def selftest_ranks(args, rank, world):
+    """`--selftest-launcher`: the multi-rank plumbing of this file on CPU tensors over gloo (no GPU, no kernels; the
+    per-evaluation sums are synthetic) -- self-launch, env parsing, one all-reduce per evaluation through
+    `PipelinedStatsReducer(bucket=1)`, barrier + max-over-ranks timing, one JSON line.  tests/test_bench_launcher.py."""
+    import torch.distributed as dist
+    from lsnf_amd import parallel
+    dist.init_process_group("gloo")
+    lo, hi = parallel.shard_bounds(B_GLOBAL, world, rank)
+    red = parallel.PipelinedStatsReducer(torch.device("cpu"), bucket=1)
+    dist.barrier()
+    t0 = time.perf_counter()
+    seen = []
+    for it in range(args.steps):
+        st = red.next_buffer()
+        if it >= 2:
+            seen.append(st[4:7].clone())              # evaluation it-2, reduced over the ranks
+        st[4], st[5], st[6] = float(it + 1) * (rank + 1), -2.0 * (rank + 1), float(hi - lo)
+        red.submit(st)
+    fin = red.finish().clone()
+    dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    tri = world * (world + 1) / 2
+    ok = (fin.tolist() == [args.steps * tri, -2.0 * tri, float(B_GLOBAL)]
+          and all(s.tolist() == [(k + 1) * tri, -2.0 * tri, float(B_GLOBAL)] for k, s in enumerate(seen)))
+    if rank == 0:
+        print(json.dumps({"selftest": True, "ok": bool(ok), "n_gpus": world, "steps": args.steps, "scaling": "strong",
+                          "rows_per_rank": hi - lo, "collectives_per_evaluation": 1, "elapsed_s": el.item()}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=300)   # the chip needs ~50 ms of sustained load to reach its steady clock
+    ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--ramp", type=int, default=600,
+                    help="untimed forward launches BEFORE the W warm-up steps that bring the chip to its steady clock (MI355X "
+                         "needs ~50 ms of sustained load: 2.07 GHz in the first ~100 launches, 2.39 GHz afterwards); reported "
+                         "in the JSON line as untimed_launches_before_timed_region = ramp + warmup; 0 disables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank logic on a box with fewer GPUs than ranks)")
-    ap.add_argument("--math", choices=["fp16x2", "bf16x3", "fp32"], default="fp16x2",
-                    help="arithmetic of the forward's GEMMs: fp16x2 = two-term fp16 split, three fp16 MFMAs per product, "
-                         "range-guarded by a bf16x3 fix-up pass (fp32-class accuracy, the library default); bf16x3 = "
-                         "error-free three-way bf16 split, six bf16 MFMAs per product; fp32 = fp32 MFMA")
+    ap.add_argument("--math", choices=["bf16x3", "fp32", "fp16x2"], default="bf16x3",
+                    help="arithmetic of the forward's GEMMs.  bf16x3 (default): error-free three-way bf16 split, 24 operand "
+                         "bits, six bf16 MFMAs per product; fp32: fp32 MFMA; fp16x2: two-term fp16 split (22 operand bits: "
+                         "narrower than the reference, opt-in only)")
     ap.add_argument("--streams", type=int, default=3,
-                    help="HIP streams the independent steps rotate over (the load head of step i+1 and the early-exit fix-up "
-                         "launch of step i overlap the store tail of step i; measured 1: 75.8, 2: 70.3, 3: 60.7, 4: 64.7, 6: 61.1 us/step)")
+                    help="HIP streams the independent steps rotate over (the load head of step i+1 overlaps the store tail of "
+                         "step i); the single-stream ms/step is measured and reported as well")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: which form is the headline `value` (the other one is timed too and reported beside it)")
+    ap.add_argument("--weak-bucket", type=int, default=32, help="evaluations per collective of the weak-scaling figure")
+    ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become one (before anything here has touched the GPU)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.selftest_launcher:
+        raise SystemExit(selftest_ranks(args, rank, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the flow path has no CPU fallback")
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
@@ -128,93 +223,114 @@ def main():
             dist.init_process_group(args.backend)
 
     import lsnf_amd
+    from lsnf_amd import parallel
     MATH = {"fp32": lsnf_amd.flow.MATH_FP32, "bf16x3": lsnf_amd.flow.MATH_BF16X3, "fp16x2": lsnf_amd.flow.MATH_FP16X2}
     lsnf_amd.flow.set_math_mode(MATH[args.math])
     weights = synth_weights(1)
     plan = lsnf_amd.prepare([w.to(dev) for w in weights], NZ, WIDTH, DEPTH)
-    z = torch.randn(B_PER_GPU, NZ, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
-    from lsnf_amd import parallel
-
-    # Steps are independent batches (synthetic z), so consecutive steps alternate over `--streams` HIP streams, each
-    # with its own output buffers: while the last workgroups of step i drain their stores, the workgroups of step
-    # i+1 already load their rows on the CUs that have become free (fp32 generation: 174 -> 164 us per step; today's
-    # fp16x2 forward, whose every launch is followed by an early-exit fix-up launch: 70.3 us at 2 streams, 60.7 at 3).  Every step is
-    # still a complete forward over 65 536 rows; K steps are timed, as the contract says.
     n_streams = max(1, args.streams)
     main_stream = torch.cuda.current_stream()
-    streams = [torch.cuda.Stream() for _ in range(n_streams)] if n_streams > 1 else [main_stream]
-    outs = [(torch.empty_like(z), torch.empty(B_PER_GPU, device=dev), torch.empty(B_PER_GPU, device=dev))
-            for _ in range(n_streams)]
-    z1, logdet, ll = outs[0]
-    # one collective per REDUCE_BUCKET evaluations of a stream (each evaluation's sums travel, bucketed): the forward
-    # kernels fill the chip exactly (one workgroup per CU), so every collective kernel delays one of their workgroups
-    REDUCE_BUCKET = 32
-    reducers = [parallel.PipelinedStatsReducer(dev, bucket=REDUCE_BUCKET) for _ in range(n_streams)]
-    counter = [0]
-    torch.cuda.synchronize()
+    side_streams = [torch.cuda.Stream() for _ in range(n_streams)]
 
-    def step():
-        # forward + log-prob; sum_b ll (train.py:320) is accumulated inside the kernel.  N > 1: the single all-reduce
-        # of that sum is submitted asynchronously and overlaps the following kernels (stats buffers alternate).
-        k = counter[0] % n_streams
-        counter[0] += 1
-        with torch.cuda.stream(streams[k]):
-            stats = reducers[k].next_buffer()
-            lsnf_amd.forward(plan, z, out=outs[k], stats=stats)
-            reducers[k].submit(stats)
-
-    def fence():
-        for k in range(n_streams):  # every outstanding all-reduce is complete before the clock is read
-            with torch.cuda.stream(streams[k]):
-                reducers[k].finish()
+    def fence(reducers, streams):
+        for red, s in zip(reducers, streams):   # every outstanding all-reduce is complete before the clock is read
+            with torch.cuda.stream(s):
+                red.finish()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Clock ramp (not steps, not timed): MI355X needs ~50 ms of sustained load before it holds its steady shader clock
-    # (2.07 GHz in the first ~100 launches, 2.39 GHz afterwards).  The metric is steady-state
-    # throughput, so the chip is brought to that state first, whatever W the caller passes.
-    RAMP_LAUNCHES = 600
-    for _ in range(RAMP_LAUNCHES):
-        lsnf_amd.forward(plan, z, out=outs[0])
-    torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    def timed(z, bucket, streams, steps, warmup):
+        """W untimed + K timed steps over `streams`; returns seconds for the K steps (max over ranks)."""
+        rows = z.shape[0]
+        outs = [(torch.empty_like(z), torch.empty(rows, device=dev), torch.empty(rows, device=dev)) for _ in streams]
+        reducers = [parallel.PipelinedStatsReducer(dev, bucket=bucket) for _ in streams]
+        counter = [0]
 
-    # kernel-only loop for the roofline: HIP events on the launch stream around K back-to-back launches
+        def step():
+            # forward + log-prob; sum_b ll (train.py:320) is accumulated inside the kernel.  N > 1: the all-reduce of the
+            # sums is submitted asynchronously on RCCL's stream and overlaps the following kernels (banks alternate)
+            k = counter[0] % len(streams)
+            counter[0] += 1
+            with torch.cuda.stream(streams[k]):
+                stats = reducers[k].next_buffer()
+                lsnf_amd.forward(plan, z, out=outs[k], stats=stats)
+                reducers[k].submit(stats)
+
+        for _ in range(warmup):
+            step()
+        fence(reducers, streams)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence(reducers, streams)
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = t.item()
+        return elapsed
+
+    gen = torch.Generator().manual_seed(1234 + rank)
+    z_weak = torch.randn(B_GLOBAL, NZ, generator=gen).to(dev)                  # 65 536 rows on every GPU
+    lo, hi = parallel.shard_bounds(B_GLOBAL, world, rank)
+    z_strong = z_weak[: hi - lo].contiguous() if world > 1 else z_weak         # this rank's slab of ONE 65 536-row evaluation
+    torch.cuda.synchronize()
+
+    # Clock ramp (not steps, not timed; counted in untimed_launches_before_timed_region)
+    tmp = (torch.empty_like(z_weak), torch.empty(B_GLOBAL, device=dev), torch.empty(B_GLOBAL, device=dev))
+    for _ in range(max(0, args.ramp)):
+        lsnf_amd.forward(plan, z_weak, out=tmp)
+    torch.cuda.synchronize()
+
+    results = {}
+    forms = ["strong", "weak"] if world > 1 else ["single"]
+    for form in forms:
+        z = z_strong if form == "strong" else z_weak
+        bucket = 1 if form != "weak" else max(1, args.weak_bucket)
+        el = timed(z, bucket, side_streams if n_streams > 1 else [main_stream], args.steps, args.warmup)
+        el1 = timed(z, bucket, [main_stream], args.steps, min(args.warmup, 20))
+        rows_all = B_GLOBAL if form != "weak" else world * B_GLOBAL
+        results[form] = {"value": rows_all * args.steps / el, "ms_per_step": el / args.steps * 1e3,
+                         "ms_per_step_single_stream": el1 / args.steps * 1e3,
+                         "value_single_stream": rows_all * args.steps / el1,
+                         "rows_per_gpu": z.shape[0], "global_rows_per_step": rows_all,
+                         "evaluations_per_collective": bucket if world > 1 else None}
+    head = results["single"] if world == 1 else results[args.scaling]
+
+    # kernel-only loop for the roofline: HIP events on the launch stream around back-to-back launches of one stream
+    z1, logdet, ll = tmp
+
     def kernel_ms(mode):
         lsnf_amd.flow.set_math_mode(MATH[mode])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(5):
-            lsnf_amd.forward(plan, z, out=(z1, logdet, ll))
+        for _ in range(10):
+            lsnf_amd.forward(plan, z_weak, out=(z1, logdet, ll))
         torch.cuda.synchronize()
-        kl = max(20, min(args.steps, 200))
+        kl = max(50, min(args.steps, 200))
         e0.record()
         for _ in range(kl):
-            lsnf_amd.forward(plan, z, out=(z1, logdet, ll))
+            lsnf_amd.forward(plan, z_weak, out=(z1, logdet, ll))
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / kl
+
     others = {}
-    for other in [m for m in ("fp32", "bf16x3", "fp16x2") if m != args.math]:   # the other arithmetic modes, reported beside the measured one
+    for other in [m for m in ("fp32", "bf16x3", "fp16x2") if m != args.math]:   # the other arithmetic modes, kernel-only
         others[other] = {"kernel_ms": kernel_ms(other)}
         others[other]["ll"] = ll.clone()
     kern_ms = kernel_ms(args.math)            # also leaves the library in the measured mode
+    flops = FLOP_PER_SAMPLE * B_GLOBAL
     for other in others:
         ll_o = others[other].pop("ll")
-        others[other]["samples_per_s_kernel_only"] = B_PER_GPU / (others[other]["kernel_ms"] * 1e-3)
-        others[other]["max_rel_ll_difference_to_measured_mode"] = ((ll - ll_o).abs() / ll.abs().clamp_min(1.0)).max().item()
+        o = others[other]
+        o["samples_per_s_kernel_only"] = B_GLOBAL / (o["kernel_ms"] * 1e-3)
+        o["algorithmic_tflops"] = flops / (o["kernel_ms"] * 1e-3) / 1e12
+        o["frac_of_its_pipe_peak"] = o["algorithmic_tflops"] / MODES[other]["peak"]
+        o["max_rel_ll_difference_to_measured_mode"] = ((ll - ll_o).abs() / ll.abs().clamp_min(1.0)).max().item()
+        if other == "fp16x2":
+            o["note"] = "opt-in mode, 22 operand bits: narrower than the reference's fp32 -- never the headline"
     # prepare (weight folding + fp64 Gauss-Jordan), amortised over the Langevin loop in production
     p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     wd = [w.to(dev) for w in weights]
@@ -226,77 +342,64 @@ def main():
     prep_ms = p0.elapsed_time(p1) / 5
 
     if rank == 0:
-        ms = elapsed / args.steps * 1e3
-        value = world * B_PER_GPU * args.steps / elapsed
-        tflops = FLOP_PER_SAMPLE * B_PER_GPU / (kern_ms * 1e-3) / 1e12          # algorithmic (fp32-equivalent) rate
-        if args.math == "fp16x2":   # 3 fp16 MFMA flops per algorithmic flop, priced against the dense fp16 peak (= the bf16 one)
-            rl = {"bound": "mfma", "achieved": 3 * tflops, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                  "frac": 3 * tflops / PEAK_BF16_MFMA_TFLOPS, "kernel": "lsnf_fwd2h_kernel<Fwd3Cfg<2,2>, 8>",
-                  "note": "executed fp16 MFMA flops (3 per algorithmic flop: operands split into two fp16 terms, products "
-                          "w1x1 + w1x2 + w2x1) vs the dense fp16 peak; algorithmic_tflops is the fp32-equivalent rate, 1.0 of "
-                          "the fp32 MFMA peak would be 157.3.  kernel_ms is measured around the launch PAIR the mode issues "
-                          "(the fp16 kernel and the bf16x3 fix-up pass behind it, which exits at once unless an operand left "
-                          "fp16's range: ~2 us).  The matrix pipe is busy about half of the kernel: the rest is the operand "
-                          "split (2 VALU per element), the coupling epilogue and the z rows in / out, none of which "
-                          "overlap MFMA issue on a SIMD (DESIGN.md section 5)"}
-        elif args.math == "bf16x3":   # the matrix pipe executes 6 bf16 MFMA flops per algorithmic flop: price THAT against the bf16 peak
-            rl = {"bound": "mfma", "achieved": SPLIT_MFMA_PER_PRODUCT * tflops, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                  "frac": SPLIT_MFMA_PER_PRODUCT * tflops / PEAK_BF16_MFMA_TFLOPS, "kernel": "lsnf_fwd3b_kernel<Fwd3Cfg<2,2>, 8>",
-                  "note": "executed bf16 MFMA flops (6 per algorithmic flop) vs the dense bf16 peak; algorithmic_tflops is "
-                          "the fp32-equivalent rate, 1.0 of the fp32 MFMA peak would be 157.3.  Calibration (tools/micro/"
-                          "mfma_bf16_shapes.hip, DESIGN.md section 5): a bare loop of this MFMA shape (16x16x32) sustains 1819 "
-                          "TFLOP/s on random operands (the chip gives clock back under the bf16 pipe: this kernel runs at "
-                          "2.0-2.2 GHz), 2234 on zeros",
-                  "bare_mfma_loop_on_random_operands_tflops": 1819.0}
-        else:
-            rl = {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                  "frac": tflops / PEAK_FP32_MFMA_TFLOPS, "kernel": "lsnf_fwd_kernel<FwdCfg<2,2>, 8>"}
+        mode = MODES[args.math]
+        tflops = flops / (kern_ms * 1e-3) / 1e12          # algorithmic (fp32-equivalent) rate, measured in this run
+        # committed profiler evidence of the same kernel (profiles/, newest round): CARRIED from files, not measured now
+        carried = {"source": "carried from profiles/ (committed rocprofv3 runs of this command), not measured in this run"}
+        try:
+            import glob
+            tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_only_from_trace.json")))[-1]
+            ent = json.load(open(tf)).get(mode["kernel"])
+            if ent:
+                us = ent["kernel_only_loop_last_200_avg_us"]
+                carried["rocprofv3_kernel_trace"] = {"file": os.path.basename(tf), "avg_us": us,
+                                                     "frac_from_trace": flops / (us * 1e-6) / 1e12 / mode["peak"]}
+        except Exception:
+            pass
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
                 traffic = (json.load(open(tfile)).get(args.math) or {}).get("hbm_bytes_per_launch")
+                carried["traffic_file"] = "profiles/traffic.json (PMC passes FETCH_SIZE x 2 + WRITE_SIZE)"
             except Exception:
                 traffic = None
-        # the committed rocprofv3 kernel-trace average of the same kernel in the same command (profiles/, newest round),
-        # next to the live HIP-event figure above
-        trace_us = None
-        try:
-            import glob
-            tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_only_from_trace.json")))[-1]
-            ent = json.load(open(tf)).get(rl["kernel"])
-            if ent:
-                trace_us = {"file": os.path.basename(tf), "avg_us": ent["kernel_only_loop_last_200_avg_us"]}
-        except Exception:
-            trace_us = None
-        rl["rocprofv3_kernel_trace"] = trace_us
+        rl = {"bound": "mfma", "achieved": tflops, "peak": mode["peak"], "unit": "TFLOP/s", "frac": tflops / mode["peak"],
+              "traffic": traffic, "kernel": mode["kernel"], "pipe": mode["pipe"],
+              "kernel_ms": kern_ms, "flop_per_launch": flops,
+              "frac_vs_fp32_mfma_peak": tflops / PEAK_FP32_MFMA_TFLOPS, "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS,
+              "matrix_pipe_utilisation": mode["exec_per_alg"] * tflops / mode["peak"],
+              "executed_mfma_flops_per_algorithmic_flop": mode["exec_per_alg"],
+              "hbm_frac_secondary": BYTES_PER_SAMPLE_FUSED * B_GLOBAL / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+              "note": "achieved = ALGORITHMIC flops (327 680 per sample, SURVEY 8d) / HIP-event time of a single-stream "
+                      "kernel-only loop of this run; frac = achieved / dense peak of the pipe the kernel runs on.  An fp32-"
+                      "accurate product costs exec_per_alg MFMAs on that pipe, so frac <= 1/exec_per_alg; "
+                      "matrix_pipe_utilisation prices the executed flops",
+              "carried": carried}
         line = {
             "metric": "latent-samples/sec through flow+logdet, nz=128 B=65536",
-            "value": value, "unit": "latent-samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"fp16x2": "fp16x2", "bf16x3": "bf16x3", "fp32": "f32"}[args.math], "data": "synthetic",
+            "value": head["value"], "unit": "latent-samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+            "scaling": "weak" if world == 1 else args.scaling,
+            "vs_baseline": None, "dtype": mode["dtype"], "data": "synthetic",
+            "ms_per_step_single_stream": head["ms_per_step_single_stream"],
+            "value_single_stream": head["value_single_stream"],
+            "untimed_launches_before_timed_region": max(0, args.ramp) + args.warmup,
             "config": {"workload": "CIFAR-10 flow prior nz=128 f_width=64 f_depth=5 affine, forward+logdet+log-prob, "
-                                   "B=65536 synthetic z per GPU (BASELINE.json configs[2])",
-                       "rows_per_gpu": B_PER_GPU, "global_rows": world * B_PER_GPU,
-                       "parallelism": (f"dp{world} (rows sharded; sum ll / sum logdet / rows of every evaluation all-reduced, "
-                                       f"{REDUCE_BUCKET} evaluations per collective)") if world > 1 else "single GPU",
-                       "streams": n_streams, "clock_ramp_launches_before_warmup": RAMP_LAUNCHES,
-                       "prepare_ms_not_in_step": prep_ms,
-                       "math": {"fp16x2": "fp16x2: every GEMM operand split into two fp16 terms (11+11 significand bits), three fp16 "
-                                          "MFMAs (16x16x32) per product, fp32 accumulation; dropped terms <= 2^-22|w||x|, log-prob "
-                                          "error vs float64 equals the fp32-MFMA kernel's (tests/test_gpu_forward.py::"
-                                          "test_split_bf16_is_fp32_faithful, ::test_split_bf16_dynamic_range); operands outside "
-                                          "fp16's range are caught in-kernel and the launch recomputed by the bf16x3 kernel "
-                                          "(::test_fp16_split_range_guard)",
-                                "bf16x3": "bf16x3: every GEMM operand split error-free into three bf16 terms, six bf16 MFMAs "
-                                          "(16x16x32) per product, fp32 accumulation; log-prob error vs float64 equals the "
-                                          "fp32-MFMA kernel's (tests/test_gpu_forward.py::test_split_bf16_is_fp32_faithful)",
-                                "fp32": "fp32 MFMA"}[args.math],
+                                   "B=65536 synthetic z per evaluation (BASELINE.json configs[2])",
+                       "rows_per_gpu": head["rows_per_gpu"], "global_rows": head["global_rows_per_step"],
+                       "parallelism": (f"dp{world}, {args.scaling} scaling: rows sharded, weights replicated; sum ll / sum logdet / "
+                                       f"rows of every evaluation all-reduced ({head['evaluations_per_collective']} "
+                                       f"evaluation(s) per collective, backend {args.backend})") if world > 1 else "single GPU",
+                       "streams": n_streams, "clock_ramp_launches_before_warmup": max(0, args.ramp),
+                       "prepare_ms_not_in_step": prep_ms, "math": MATH_TEXT[args.math],
                        "other_math_modes": others},
-            "roofline": dict(rl, traffic=traffic, kernel_ms=kern_ms, flop_per_launch=FLOP_PER_SAMPLE * B_PER_GPU,
-                             algorithmic_tflops=tflops, fp32_mfma_peak=PEAK_FP32_MFMA_TFLOPS,
-                             hbm_frac_secondary=BYTES_PER_SAMPLE_FUSED * B_PER_GPU / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS),
+            "roofline": rl,
         }
+        if world > 1:
+            other_form = "weak" if args.scaling == "strong" else "strong"
+            line[other_form + "_scaling"] = results[other_form]
+            line["ranks_seen_by_backend"] = dist.get_world_size()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(weights)
         print(json.dumps(line), flush=True)

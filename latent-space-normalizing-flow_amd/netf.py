@@ -127,7 +127,7 @@ class _ParamGate(torch.autograd.Function):
         h, module = ctx.holder, ctx.module
         if h.z1 is None:
             raise LsnfError("parameter gradients requested before the flow's backward ran")
-        if module._plan_key != h.plan_key:
+        if module._current_key() != h.plan_key:     # the LIVE parameters, not the key cached at the last _plan() call
             raise LsnfError("flow parameters were modified between forward and backward")
         grads = flow.backward_params(module._plan(), module._param_list(), h.z, h.z1, h.saved, h.g_z1, h.g_logdet)
         grads = [g if need else None for g, need in zip(grads, ctx.needs_input_grad[2:])]
@@ -155,7 +155,9 @@ class _FlowStackFn(torch.autograd.Function):
     def backward(ctx, g_z1, g_logdet):
         module, h = ctx.module, ctx.holder
         z, z1, saved = ctx.saved_tensors
-        if module._plan_key != ctx.plan_key:
+        if module._current_key() != ctx.plan_key:   # the LIVE parameters: an optimizer step / load_state_dict / EMA copy
+            # between forward and backward would otherwise re-prepare the plan in place and pair new weights with the
+            # activations saved from the old ones (PyTorch autograd raises a version-counter error in the same situation)
             raise LsnfError("flow parameters were modified between forward and backward")
         saved_t = saved if saved.numel() else None
         g_z1 = None if g_z1 is None else g_z1.contiguous()
@@ -203,14 +205,29 @@ class _netF(nn.Module):
         self._cached_plan, self._plan_key = None, None
         return super()._apply(fn, *args, **kwargs)
 
+    def _current_key(self):
+        """Identity of the live parameter values as autograd sees them: (storage address, version counter) per tensor.
+        In-place updates through the Parameter (optimizer steps, `load_state_dict`, `p.mul_()` under no_grad) bump the
+        version; writes through `p.data` (`p.data.copy_()`, `p.data.clamp_()`) do NOT -- `.data` has its own counter --
+        so code that edits weights that way must call `invalidate_plan()`."""
+        return tuple((p.data_ptr(), p._version) for p in self._param_list())
+
+    def invalidate_plan(self) -> None:
+        """Force the next call to re-derive the prepared weights (after writes through `p.data`, which no version
+        counter records)."""
+        self._plan_key = None
+
+    @staticmethod
+    def _require_gpu(params) -> None:
+        for p in params:
+            if not p.is_cuda:
+                raise LsnfError("_netF lives on %s: move it to the GPU (netF.to(device)); there is no CPU path" % p.device)
+
     def _plan(self) -> flow.FlowPlan:
         params = self._param_list()
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        key = self._current_key()
         if self._cached_plan is None or key != self._plan_key or self._cached_plan.device != params[0].device:
-            for p in params:
-                if not p.is_cuda:
-                    raise LsnfError("_netF lives on %s: move it to the GPU (netF.to(device)); there is no CPU path"
-                                    % p.device)
+            self._require_gpu(params)
             reuse = self._cached_plan if (self._cached_plan is not None and
                                           self._cached_plan.device == params[0].device) else None
             with torch.no_grad():

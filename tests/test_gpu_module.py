@@ -172,3 +172,29 @@ def test_params_and_z_grads_in_one_backward(lsnf, kernels, gpu_device):
     k = O.block_prefix(2) + "invertible_1x1_conv.w"
     ref = g["grad/" + k] * B                                          # fixture holds d(-mean ll); here d(-sum ll)
     assert np.linalg.norm(named[k].grad.cpu().numpy() - ref) <= 1e-4 * np.linalg.norm(ref)
+
+
+def test_parameter_update_between_forward_and_backward_raises_on_device(lsnf, gpu_device):
+    """forward -> optimizer step -> backward must raise (PyTorch autograd would) instead of re-preparing the
+    plan in place and pairing new weights with the activations saved from the old ones."""
+    p, g = load_golden("c1_nz100_w64_B256")
+    net, nz = make_net(lsnf, p, g, gpu_device)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    z = torch.from_numpy(g["z"]).to(gpu_device).requires_grad_(True)
+    z1, logdet, _ = net(z, torch.zeros(z.shape[0], device=gpu_device))
+    (-ll_of(z1, logdet).mean()).backward()
+    g_first = z.grad.clone()
+    opt.step()
+    z1, logdet, _ = net(z, torch.zeros(z.shape[0], device=gpu_device))
+    opt.step()                                    # out of order: the weights the forward used are gone
+    with pytest.raises(lsnf.LsnfError, match="modified between forward and backward"):
+        (-ll_of(z1, logdet).mean()).backward()
+    # .data writes are invisible to the version counter: invalidate_plan() makes the next forward see them
+    with torch.no_grad():
+        _, ld0, _ = net(z.detach(), torch.zeros(z.shape[0], device=gpu_device))
+    net._param_list()[1].data.add_(0.25)          # block 0 actnorm.logs: logdet moves by 3 * 0.25 * nz
+    net.invalidate_plan()
+    with torch.no_grad():
+        _, ld1, _ = net(z.detach(), torch.zeros(z.shape[0], device=gpu_device))
+    assert torch.allclose(ld1 - ld0, torch.full_like(ld0, 3 * 0.25 * nz), atol=2e-3)
+    assert torch.isfinite(g_first).all()

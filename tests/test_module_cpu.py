@@ -154,3 +154,57 @@ def test_generator_mirror_matches_reference_golden():
         assert (zg - ref).norm().item() <= 1e-4 * ref.norm().item()
     with pytest.raises(ValueError):
         netg._netG(types.SimpleNamespace(dataset="mnist", nz=8, ngf=2, nc=1, g_activation="lrelu", g_batchnorm=False))
+
+
+def _mock_kernels(monkeypatch):
+    """Stand-ins for the HIP entry points so that the autograd bridge's bookkeeping (not its numbers) runs on CPU."""
+    from lsnf_amd import netf
+    calls = {"prepare": 0}
+
+    def fake_prepare(tensors, nz, width, depth, coupling, plan=None):
+        calls["prepare"] += 1
+        return types.SimpleNamespace(device=tensors[0].device, nz=nz, depth=depth)
+    monkeypatch.setattr(netf._netF, "_require_gpu", staticmethod(lambda params: None))
+    monkeypatch.setattr(netf.flow, "prepare", fake_prepare)
+    monkeypatch.setattr(netf.flow, "new_act_saved", lambda plan, B, dev: torch.zeros(1))
+    monkeypatch.setattr(netf.flow, "forward", lambda plan, z, obj, **kw: (z * 2.0, obj + 1.0, None, torch.zeros(1, *z.shape)))
+    monkeypatch.setattr(netf.flow, "backward_z", lambda plan, z1, saved, g1, gl, act_saved=None: torch.ones_like(z1))
+    monkeypatch.setattr(netf.flow, "backward_params",
+                        lambda plan, params, *a, **k: [torch.zeros_like(p) for p in params])
+    return calls
+
+
+def test_parameter_update_between_forward_and_backward_raises(monkeypatch):
+    """the stale-weights guard must look at the LIVE parameters.  forward -> optimizer step ->
+    backward used to pass the check (the cached key was only refreshed inside _plan()) and then re-prepare the plan in
+    place: new weights against old activations.  PyTorch autograd raises in the same situation."""
+    calls = _mock_kernels(monkeypatch)
+    net = lsnf_amd._netF(hps(4, depth=2), nz=8)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    z = torch.randn(3, 8, requires_grad=True)
+    # (a) the normal order works: forward, backward (z and parameters), step
+    z1, ld, _ = net(z, torch.zeros(3))
+    (z1.sum() + ld.sum()).backward()
+    assert calls["prepare"] == 1 and torch.equal(z.grad, torch.ones(3, 8))
+    opt.step()
+    # (b) a step between forward and backward: both autograd nodes refuse
+    z1, ld, _ = net(z, torch.zeros(3))
+    assert calls["prepare"] == 2                        # the step above was seen by the forward
+    opt.step()
+    with pytest.raises(lsnf_amd.LsnfError, match="modified between forward and backward"):
+        (z1.sum() + ld.sum()).backward()
+    assert calls["prepare"] == 2                        # and the plan was NOT re-prepared under the pending backward
+    # (c) load_state_dict between forward and backward
+    z1, ld, _ = net(z, torch.zeros(3))
+    net.load_state_dict(net.state_dict())
+    with pytest.raises(lsnf_amd.LsnfError, match="modified between forward and backward"):
+        torch.autograd.grad(z1.sum(), z)
+    # (d) writes through .data are invisible to the version counter: invalidate_plan() is the documented way
+    net(z, torch.zeros(3))
+    n = calls["prepare"]
+    net._param_list()[0].data.mul_(2.0)
+    net(z, torch.zeros(3))
+    assert calls["prepare"] == n
+    net.invalidate_plan()
+    net(z, torch.zeros(3))
+    assert calls["prepare"] == n + 1
