@@ -11,8 +11,10 @@
  *   - every `const float*` / `float*` below is a DEVICE pointer (HBM) unless the name ends
  *     in `_host`; tensors are dense row-major fp32: z is (B, nz), per-sample vectors are (B,).
  *   - `stream` is a `hipStream_t` passed as `void*` (NULL = the null stream).  Calls are
- *     asynchronous, do not synchronise the device and keep no global mutable state, so they
- *     are re-entrant per stream and hipGraph-capturable (no allocation inside).
+ *     asynchronous, do not synchronise the device and write only the buffers named as outputs
+ *     (the plan is read-only after lsnf_prepare), so they are re-entrant per stream and
+ *     hipGraph-capturable (no allocation inside).  The only process-wide state are the two
+ *     tuning knobs below (lsnf_set_small_batch_max, lsnf_set_math_mode): atomics, read once per call.
  *   - return value: 0 on success, a negative LSNF_E_* code on failure; `lsnf_last_error()`
  *     returns a thread-local message.  Nothing falls back to a CPU path.
  *
@@ -30,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LSNF_ABI_VERSION 3
+#define LSNF_ABI_VERSION 4
 
 #define LSNF_OK 0
 #define LSNF_E_ARG (-1)       /* bad argument (NULL pointer, size out of range, misaligned) */
@@ -60,37 +62,46 @@ int lsnf_abi_version(void);
 const char* lsnf_last_error(void);
 
 /* Tuning knob: batches of at most `rows` rows run on the small-batch (latency) kernels, larger ones on the
- * throughput kernels; both compute the same function (results agree to fp32 rounding, not bit for bit).
- * rows < 0 only queries.  Returns the previous value (default 16384, or the LSNF_SMALL_MAX environment variable).
- * While the threshold is the built-in default, lsnf_forward in LSNF_MATH_FP16X2 switches at 12288 rows already (its
- * fp16 throughput kernel is the faster one from there); a threshold set here or by LSNF_SMALL_MAX applies as given.
- */
+ * throughput kernels; both compute the same function (results agree to fp32 rounding, not bit for bit).  ONE threshold
+ * for every entry point, so the kernel family that writes an activation stash is the one that reads it.
+ *   rows >= 0                 : set the threshold (0 disables the latency kernels); returns the previous SETTING
+ *   LSNF_SMALL_BATCH_AUTO (-2): back to the built-in crossover of the arithmetic mode in force (16384 rows; 12288 in
+ *                               LSNF_MATH_FP16X2) -- the initial state unless the LSNF_SMALL_MAX environment variable is set;
+ *                               returns the previous setting
+ *   -1                        : query only: returns the threshold in force (a row count)
+ * "previous setting" is a row count or LSNF_SMALL_BATCH_AUTO, so `prev = set(x); ...; set(prev)` restores exactly. */
+#define LSNF_SMALL_BATCH_AUTO (-2)
 int lsnf_set_small_batch_max(int rows);
 
-/* Arithmetic of the GEMMs.  Affects the forward, the backward-from-the-stash and the reverse (both families); the
- * parameter gradients and the recomputing backward (no stash given) are fp32 MFMA in every mode:
- *   LSNF_MATH_FP32   : fp32 MFMA (v_mfma_f32_32x32x2_f32)
- *   LSNF_MATH_BF16X3 : both operands split error-free into three bf16 terms, six bf16 MFMAs per product with fp32
- *                      accumulation (csrc/lsnf_fwd3.hip, on v_mfma_f32_16x16x32_bf16).  Same accuracy class as fp32
- *                      MFMA (dropped terms are <= 2^-26 |w||x|); results agree with LSNF_MATH_FP32 to fp32 rounding,
- *                      not bit for bit.
- *   LSNF_MATH_BF16X3_32 : the same scheme on v_mfma_f32_32x32x16_bf16 in the throughput forward (kept for comparison:
+/* Arithmetic of the GEMMs.  Affects the forward, the backward and the reverse (both kernel families); the parameter-
+ * gradient contraction over the batch is fp32 MFMA in every mode:
+ *   LSNF_MATH_BF16X3 : (default) both operands split error-free into three bf16 terms (3 x 8 = 24 significand bits,
+ *                      fp32's exponent range), six bf16 MFMAs per product with fp32 accumulation (csrc/lsnf_fwd3.hip, on
+ *                      v_mfma_f32_16x16x32_bf16).  Same accuracy class as fp32 MFMA (dropped terms <= 2^-26 |w||x|);
+ *                      results agree with LSNF_MATH_FP32 to fp32 rounding, not bit for bit.
+ *   LSNF_MATH_FP32   : fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere.
+ *   LSNF_MATH_BF16X3_32 : the bf16x3 scheme on v_mfma_f32_32x32x16_bf16 in the throughput forward (kept for comparison:
  *                      that shape sustains a lower clock on real data, ~8 % slower); latency forward as LSNF_MATH_FP32.
- *   LSNF_MATH_FP16X2 : (default) throughput forward and reverse with both operands split into TWO fp16 terms, three fp16 MFMAs
- *                      per product (csrc/lsnf_fwd2h.hip; dropped terms <= 2^-22 |w||x|: below the accumulated fp32
- *                      rounding of the dot products, log-prob error vs float64 as LSNF_MATH_FP32); half the matrix work
- *                      of LSNF_MATH_BF16X3.  fp16's range is guarded: a launch in which an operand (or a folded weight)
- *                      reaches 65504 is recomputed by the LSNF_MATH_BF16X3 kernel queued behind it (an early-exit
- *                      launch otherwise), so results are finite wherever the fp32 computation's are; in-place calls
- *                      (z_out == z_in) use LSNF_MATH_BF16X3 directly.  Every other kernel (latency kernels, backward)
- *                      as LSNF_MATH_BF16X3.
+ *   LSNF_MATH_BF16X3_PIPE : as LSNF_MATH_BF16X3, the throughput forward (calls without stash / block outputs, nz > 64,
+ *                      width <= 64) on csrc/lsnf_fwd3p.hip: 32x32x16 MFMAs with the operand split and the coupling
+ *                      epilogue software-pipelined between them.  Fewer cycles, lower sustained clock: measured equal
+ *                      or slower than LSNF_MATH_BF16X3; kept as the reference point for that finding.
+ *   LSNF_MATH_FP16X2 : (opt-in; NARROWER than the reference's fp32: 11 + 11 operand bits) throughput forward and reverse
+ *                      with both operands split into two fp16 terms, three fp16 MFMAs per product (csrc/lsnf_fwd2h.hip;
+ *                      dropped terms <= 2^-22 |w||x|); half the matrix work of LSNF_MATH_BF16X3.  fp16's range is
+ *                      guarded: a wave that meets an operand (or folded weight) at or beyond 65504 flags its first output
+ *                      element, and the LSNF_MATH_BF16X3 kernel queued behind the launch recomputes the flagged
+ *                      workgroups (an early-exit launch otherwise), so results are finite wherever the fp32
+ *                      computation's are.  In-place calls (z_out == z_in) and calls with in-kernel batch sums (`stats`)
+ *                      run LSNF_MATH_BF16X3 directly.  Every other kernel (latency kernels, backward) as LSNF_MATH_BF16X3.
  * mode < 0 only queries.  Returns the previous mode (default LSNF_MATH_DEFAULT, or the LSNF_MATH environment
- * variable "fp32" / "bf16x3" / "bf16x3_32" / "fp16x2"). */
+ * variable "fp32" / "bf16x3" / "bf16x3_32" / "bf16x3_pipe" / "fp16x2"). */
 #define LSNF_MATH_FP32 0
 #define LSNF_MATH_BF16X3 1
 #define LSNF_MATH_BF16X3_32 2
 #define LSNF_MATH_FP16X2 3
-#define LSNF_MATH_DEFAULT LSNF_MATH_FP16X2
+#define LSNF_MATH_BF16X3_PIPE 4
+#define LSNF_MATH_DEFAULT LSNF_MATH_BF16X3
 int lsnf_set_math_mode(int mode);
 
 /* Device query: writes the gfx arch name (e.g. "gfx950") of device `device`; LSNF_E_NODEVICE
@@ -102,9 +113,8 @@ int lsnf_device_arch(int device, char* buf, size_t buflen);
  * exp(3*logs) folding of the three actnorms (model.py:264-268), de-interleave of fc_zeros'
  * shift / scale columns (model.py:411-413), log|det W| in float64 (model.py:182), W^-1
  * (model.py:193), all re-laid-out in MFMA-fragment order.  Valid until a parameter changes.
- * The buffer ends with 1 KiB of guard words that lsnf_forward / lsnf_reverse WRITE in LSNF_MATH_FP16X2 (range-guard
- * flags of the launches in flight, see lsnf_set_math_mode; hence `const float* plan` there means "weights not modified"):
- * keep the plan in ordinary read-write device memory and do not share one plan buffer between devices. */
+ * Written by lsnf_prepare only: every other entry point reads it (`const float* plan` means const), so one plan may be
+ * shared by any number of streams and captured graphs.  Do not share one plan buffer between devices. */
 
 /* Size in floats of the prepared-weight buffer for this geometry (0 on bad geometry). */
 size_t lsnf_plan_floats(int nz, int width, int depth, int coupling);

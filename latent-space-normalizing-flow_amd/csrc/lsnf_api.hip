@@ -25,11 +25,14 @@ hipError_t lsnf_launch_forward(const LsnfGeo& g, const float* plan, int first_bl
 hipError_t lsnf_launch_forward3(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                 const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                 float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
-                                int shape16, unsigned* guard, unsigned guard_id, hipStream_t stream);
+                                int shape16, int fixup, hipStream_t stream);
+hipError_t lsnf_launch_forward3p(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
+                                 const float* z_in, const float* objective, float* z_out, float* logdet_out,
+                                 float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4, hipStream_t stream);
 hipError_t lsnf_launch_forward2h(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                  const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                  float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
-                                 int shape16, unsigned* guard, unsigned guard_id, hipStream_t stream);
+                                 int shape16, int fixup, hipStream_t stream);
 hipError_t lsnf_launch_small3_forward(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                       const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                       float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
@@ -47,9 +50,9 @@ hipError_t lsnf_launch_backward_z(const LsnfGeo& g, const float* plan, int B, co
 hipError_t lsnf_launch_small3_reverse(const LsnfGeo& g, const float* plan, int B, const float* z_in, const float* objective,
                                       float* z_out, float* objective_out, int vec4, hipStream_t stream);
 hipError_t lsnf_launch_reverse3(const LsnfGeo& g, const float* plan, int B, const float* z_in, const float* objective,
-                                float* z_out, float* objective_out, int vec4, unsigned* guard, unsigned guard_id, hipStream_t stream);
+                                float* z_out, float* objective_out, int vec4, int fixup, hipStream_t stream);
 hipError_t lsnf_launch_reverse2h(const LsnfGeo& g, const float* plan, int B, const float* z_in, const float* objective,
-                                 float* z_out, float* objective_out, int vec4, unsigned* guard, unsigned guard_id, hipStream_t stream);
+                                 float* z_out, float* objective_out, int vec4, int fixup, hipStream_t stream);
 hipError_t lsnf_launch_small_reverse(const LsnfGeo& g, const float* plan, int B, const float* z_in, const float* objective,
                                      float* z_out, float* objective_out, int vec4, hipStream_t stream);
 hipError_t lsnf_launch_small_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
@@ -93,33 +96,48 @@ int row_vector_width(const LsnfGeo& g, std::initializer_list<const void*> rows) 
 }
 bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
 
-// rows at or below which the small-batch kernels are used (LSNF_SMALL_MAX overrides; 0 disables them)
-int g_small_max = -1;
-bool g_small_max_set = false;      // threshold chosen by the caller (lsnf_set_small_batch_max / LSNF_SMALL_MAX)
-int small_batch_max() {
-    if (g_small_max < 0) { const char* e = getenv("LSNF_SMALL_MAX"); g_small_max = e ? atoi(e) : LSNF_SMALL_MAX_DEFAULT; g_small_max_set = e != nullptr; }
-    return g_small_max;
-}
-
-// arithmetic of the throughput forward's GEMMs (LSNF_MATH=fp32|bf16x3 overrides the default)
-int g_math = -1;
+// arithmetic of the GEMMs (LSNF_MATH=fp32|bf16x3|bf16x3_32|bf16x3_pipe|fp16x2 overrides the default).  The two knobs are
+// process-wide settings read by every call: atomics, so that a setter on one thread and a launch on another do not race
+// (a launch sees the old or the new value, never a torn one).
+std::atomic<int> g_math{-1};
 int math_mode() {
-    if (g_math < 0) {
+    int m = g_math.load(std::memory_order_relaxed);
+    if (m < 0) {
         const char* e = getenv("LSNF_MATH");
-        g_math = (e && !strcmp(e, "bf16x3")) ? LSNF_MATH_BF16X3 : (e && !strcmp(e, "bf16x3_32")) ? LSNF_MATH_BF16X3_32
-               : (e && !strcmp(e, "fp16x2")) ? LSNF_MATH_FP16X2 : (e && !strcmp(e, "fp32")) ? LSNF_MATH_FP32 : LSNF_MATH_DEFAULT;
+        m = (e && !strcmp(e, "bf16x3")) ? LSNF_MATH_BF16X3 : (e && !strcmp(e, "bf16x3_32")) ? LSNF_MATH_BF16X3_32
+          : (e && !strcmp(e, "bf16x3_pipe")) ? LSNF_MATH_BF16X3_PIPE
+          : (e && !strcmp(e, "fp16x2")) ? LSNF_MATH_FP16X2 : (e && !strcmp(e, "fp32")) ? LSNF_MATH_FP32 : LSNF_MATH_DEFAULT;
+        int expected = -1;
+        g_math.compare_exchange_strong(expected, m, std::memory_order_relaxed);
+        m = g_math.load(std::memory_order_relaxed);
     }
-    return g_math;
+    return m;
 }
-// modes whose latency / backward / reverse kernels are the bf16x3 "L16" ones (LSNF_MATH_FP16X2 changes the throughput forward only)
-// ids of the range-guarded fp16 launches (slot and flag value of their fix-up pass); 0 means "no fix-up due"
-unsigned next_launch_id() {
-    static std::atomic<unsigned> launch_id{0};
-    unsigned id = ++launch_id;
-    if (id == 0) id = ++launch_id;
-    return id;
+// rows at or below which the small-batch (latency) kernels are used: LSNF_SMALL_BATCH_AUTO = the measured crossover of
+// the arithmetic mode in force -- ONE threshold for the forward, the backward, the Langevin step and the reverse, so the
+// kernel family that wrote an activation stash is the family that reads it (LSNF_SMALL_MAX overrides; 0 disables them)
+std::atomic<int> g_small_max{-3};                 // -3: not initialised; LSNF_SMALL_BATCH_AUTO; or the rows set by the caller
+int small_batch_setting() {
+    int v = g_small_max.load(std::memory_order_relaxed);
+    if (v == -3) {
+        const char* e = getenv("LSNF_SMALL_MAX");
+        int init = e ? atoi(e) : LSNF_SMALL_BATCH_AUTO;
+        if (init < 0) init = LSNF_SMALL_BATCH_AUTO;
+        int expected = -3;
+        g_small_max.compare_exchange_strong(expected, init, std::memory_order_relaxed);
+        v = g_small_max.load(std::memory_order_relaxed);
+    }
+    return v;
 }
-bool l16_math() { return math_mode() == LSNF_MATH_BF16X3 || math_mode() == LSNF_MATH_FP16X2; }
+int small_batch_max() {
+    const int v = small_batch_setting();
+    if (v != LSNF_SMALL_BATCH_AUTO) return v;
+    // fp16x2: its throughput forward is the faster one from ~12 K rows (profiles/r01_i_crossover.txt: 40.8 vs 41.9 us at
+    // 12 288, 42.5 vs 51.6 at 16 384); every other mode: ~18-20 K (profiles/r01_g_crossover.txt)
+    return math_mode() == LSNF_MATH_FP16X2 ? 12288 : LSNF_SMALL_MAX_DEFAULT;
+}
+// modes whose latency / backward / reverse kernels are the bf16x3 "L16" ones
+bool l16_math() { const int m = math_mode(); return m == LSNF_MATH_BF16X3 || m == LSNF_MATH_FP16X2 || m == LSNF_MATH_BF16X3_PIPE; }
 
 int geo_or_fail(LsnfGeo* g, int nz, int width, int depth, int coupling) {
     if (lsnf_geo_init(g, nz, width, depth, coupling))
@@ -135,13 +153,16 @@ extern "C" {
 int lsnf_abi_version(void) { return LSNF_ABI_VERSION; }
 
 int lsnf_set_small_batch_max(int rows) {
-    const int prev = small_batch_max();
-    if (rows >= 0) { g_small_max = rows; g_small_max_set = true; }
+    if (rows == -1) return small_batch_max();                      // query: the threshold in force
+    const int prev = small_batch_setting();                        // what was SET: rows, or LSNF_SMALL_BATCH_AUTO
+    if (rows >= 0 || rows == LSNF_SMALL_BATCH_AUTO) g_small_max.store(rows, std::memory_order_relaxed);
     return prev;
 }
 int lsnf_set_math_mode(int mode) {
     const int prev = math_mode();
-    if (mode == LSNF_MATH_FP32 || mode == LSNF_MATH_BF16X3 || mode == LSNF_MATH_BF16X3_32 || mode == LSNF_MATH_FP16X2) g_math = mode;
+    if (mode == LSNF_MATH_FP32 || mode == LSNF_MATH_BF16X3 || mode == LSNF_MATH_BF16X3_32 || mode == LSNF_MATH_FP16X2 ||
+        mode == LSNF_MATH_BF16X3_PIPE)
+        g_math.store(mode, std::memory_order_relaxed);
     return prev;
 }
 const char* lsnf_last_error(void) { return g_err; }
@@ -208,12 +229,9 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
     // batch-size dispatch: latency kernel (32 rows per workgroup, stages split over the 4 waves) below the
     // crossover, throughput kernel (128 rows per workgroup, weights shared through LDS) above it
     hipError_t e;
-    const bool split = math_mode() == LSNF_MATH_BF16X3 || math_mode() == LSNF_MATH_BF16X3_32;
-    // the fp16x2 throughput forward is the faster one from ~12 K rows (profiles/r01_i_crossover.txt: 40.8 vs 41.9 us at
-    // 12 288, 42.5 vs 51.6 at 16 384) -- used unless the caller has chosen the threshold
-    int fwd_small_max = small_batch_max();
-    if (math_mode() == LSNF_MATH_FP16X2 && !g_small_max_set && fwd_small_max > 12288) fwd_small_max = 12288;
-    if (B <= fwd_small_max) {
+    const int math = math_mode();
+    const bool split = math == LSNF_MATH_BF16X3 || math == LSNF_MATH_BF16X3_32 || math == LSNF_MATH_BF16X3_PIPE;
+    if (B <= small_batch_max()) {
         e = hipErrorInvalidValue;
         if (l16_math())                           // latency forward on the bf16 pipe: 16-sample workgroups (lsnf_small3_fwd.hip)
             e = lsnf_launch_small3_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
@@ -223,21 +241,25 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
                                           z_saved, act_saved, stats, vec4, (hipStream_t)stream);
     } else {
         e = hipErrorInvalidValue;
-        // (the fix-up pass re-reads the inputs: not for in-place calls)
-        const bool fp16_ok = math_mode() == LSNF_MATH_FP16X2 && z_in != z_out && (objective == nullptr || objective != logdet_out);
-        if (fp16_ok) {                            // two fp16 terms per operand, three MFMAs per product (lsnf_fwd2h.hip) ...
-            unsigned* guard = reinterpret_cast<unsigned*>(const_cast<float*>(plan) + g.off_guard);
-            const unsigned id = next_launch_id();
+        // fp16x2 (opt-in): two fp16 terms per operand, three MFMAs per product (lsnf_fwd2h.hip), followed by the bf16x3 kernel
+        // as a fix-up pass that recomputes the workgroups in which a wave met an operand outside fp16's range (the flag
+        // travels in logdet_out) and exits at once elsewhere.  Not for in-place calls (the fix-up re-reads the inputs) and
+        // not with in-kernel batch sums (a partial recomputation cannot repair them): those run bf16x3 directly.
+        const bool fp16_ok = math == LSNF_MATH_FP16X2 && stats == nullptr && z_in != z_out &&
+                             (objective == nullptr || objective != logdet_out);
+        if (fp16_ok) {
             e = lsnf_launch_forward2h(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
-                                      z_saved, act_saved, stats, vec4, 1, guard, id, (hipStream_t)stream);
-            if (e == hipSuccess)                  // ... and the bf16x3 fix-up pass behind it: exits at once unless the fp16
-                                                  // kernel met an operand outside fp16's range, else recomputes every row
+                                      z_saved, act_saved, nullptr, vec4, 1, 0, (hipStream_t)stream);
+            if (e == hipSuccess)
                 e = lsnf_launch_forward3(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
-                                         z_saved, act_saved, stats, vec4, 1, guard, id, (hipStream_t)stream);
+                                         z_saved, act_saved, nullptr, vec4, 1, /*fixup=*/1, (hipStream_t)stream);
         }
-        if (split || (e == hipErrorInvalidValue && math_mode() == LSNF_MATH_FP16X2))   // error-free split on the bf16 matrix pipe (lsnf_fwd3.hip)
+        if (math == LSNF_MATH_BF16X3_PIPE)        // the 32x32x16 kernel with its vector work pipelined under the MFMAs (lsnf_fwd3p.hip)
+            e = lsnf_launch_forward3p(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
+                                      z_saved, act_saved, stats, vec4, (hipStream_t)stream);
+        if (e == hipErrorInvalidValue && (split || math == LSNF_MATH_FP16X2))   // error-free split on the bf16 matrix pipe (lsnf_fwd3.hip)
             e = lsnf_launch_forward3(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
-                                     z_saved, act_saved, stats, vec4, math_mode() != LSNF_MATH_BF16X3_32, nullptr, 0u, (hipStream_t)stream);
+                                     z_saved, act_saved, stats, vec4, math != LSNF_MATH_BF16X3_32, /*fixup=*/0, (hipStream_t)stream);
         if (e == hipErrorInvalidValue)            // fp32 MFMA kernel (also: stacks too deep for fwd3's LDS budget)
             e = lsnf_launch_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
                                     z_saved, act_saved, stats, vec4, (hipStream_t)stream);
@@ -268,14 +290,12 @@ int lsnf_reverse(const float* plan, int nz, int width, int depth, int coupling, 
     if (l16_math()) {        // on the bf16 pipe: lsnf_small3_rev.hip / lsnf_rev3.hip
         // fp16 two-term split (lsnf_rev2h.hip) + the bf16x3 kernel behind it as the early-exit fix-up pass, as in lsnf_forward
         if (B > small_batch_max() && math_mode() == LSNF_MATH_FP16X2 && z_in != z_out && (objective == nullptr || objective != objective_out)) {
-            unsigned* guard = reinterpret_cast<unsigned*>(const_cast<float*>(plan) + g.off_guard);
-            const unsigned id = next_launch_id();
-            e = lsnf_launch_reverse2h(g, plan, B, z_in, objective, z_out, objective_out, vec4, guard, id, (hipStream_t)stream);
+            e = lsnf_launch_reverse2h(g, plan, B, z_in, objective, z_out, objective_out, vec4, 0, (hipStream_t)stream);
             if (e == hipSuccess)
-                e = lsnf_launch_reverse3(g, plan, B, z_in, objective, z_out, objective_out, vec4, guard, id, (hipStream_t)stream);
+                e = lsnf_launch_reverse3(g, plan, B, z_in, objective, z_out, objective_out, vec4, /*fixup=*/1, (hipStream_t)stream);
         }
         if (B > small_batch_max() && e == hipErrorInvalidValue)
-            e = lsnf_launch_reverse3(g, plan, B, z_in, objective, z_out, objective_out, vec4, nullptr, 0u, (hipStream_t)stream);
+            e = lsnf_launch_reverse3(g, plan, B, z_in, objective, z_out, objective_out, vec4, /*fixup=*/0, (hipStream_t)stream);
         // (the latency form is also faster than the fp32 throughput reverse where the bf16 throughput form does not fit)
         if (e == hipErrorInvalidValue && small_batch_max() > 0)
             e = lsnf_launch_small3_reverse(g, plan, B, z_in, objective, z_out, objective_out, vec4, (hipStream_t)stream);

@@ -44,10 +44,10 @@ struct Fwd3Args {
     double* stats;
     unsigned long long* stamps;        // LSNF_STAMPS diagnostic build only: [waves & 2047][64] clock stamps
     int shape16;                       // 1: the v_mfma_f32_16x16x32_bf16 variant (panels3 then points at its operand order)
-    unsigned* guard;                   // fp16 range guard (lsnf_layout.h off_guard) or nullptr.  fp16x2 kernel: writes its
-    unsigned guard_id;                 // launch id into its slot's flag; bf16x3 L16 kernel: runs only if the flag holds
-                                       // that id (the fix-up pass), then clears it.  Slots are per launch id, so launches
-                                       // of one plan in flight on several streams do not see each other's flags
+    const unsigned* guard;             // fp16x2 kernel: the plan's guard words ([0]: weights outside fp16's range), read only
+    int fixup;                         // bf16x3 L16 kernel: 1 = run as the fix-up pass of an fp16x2 launch: a workgroup
+                                       // recomputes its rows only if one of its waves left LSNF_F16_SENTINEL_BITS in
+                                       // logdet_out (lsnf_layout.h); the flag travels in the launch's own output
 };
 
 #ifdef LSNF_STAMPS   // in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz (tools/stamps_fwd3.py)
@@ -347,13 +347,23 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3b_kernel(const Fwd3
 
     F3_STAMP(0, "s_memtime");
     F3_STAMP(50, "s_memrealtime");
+    const long wbase = ((long)blockIdx.x * F3_WAVES + wave) * 32;     // first row of this wave
 #if LSNF_L16_PARTS == 3
-    unsigned* const gslot = a.guard ? a.guard + 2 * (1 + a.guard_id % LSNF_GUARD_SLOTS) : nullptr;
-    if (gslot && gslot[0] != a.guard_id) return;  // fix-up pass of the fp16 forward: nothing overflowed (kernel-uniform)
+    if (a.fixup) {                                // fix-up pass of the fp16 forward: only workgroups in which a wave raised its flag
+        unsigned* fl = reinterpret_cast<unsigned*>(smem);
+        unsigned f = 0u;
+        if (wbase < a.B) f = __builtin_bit_cast(unsigned, a.logdet_out[wbase]) == LSNF_F16_SENTINEL_BITS ? 1u : 0u;
+        if (lane == 0) fl[wave] = f;
+        __syncthreads();
+        unsigned any = 0u;
+#pragma unroll
+        for (int w = 0; w < F3_WAVES; ++w) any |= fl[w];
+        __syncthreads();                          // (smem is reused below)
+        if (any == 0u) return;                    // workgroup-uniform
+    }
 #else
-    unsigned* const gslot = a.guard + 2 * (1 + a.guard_id % LSNF_GUARD_SLOTS);
-    if (a.guard[0] != 0u) {                       // weights outside fp16's range (prepare): leave everything to the fix-up pass
-        if (tid == 0) gslot[0] = a.guard_id;
+    if (a.guard[0] != 0u) {                       // weights outside fp16's range (prepare): leave every row to the fix-up pass
+        if (lane == 0 && wbase < a.B) a.logdet_out[wbase] = __builtin_bit_cast(float, LSNF_F16_SENTINEL_BITS);
         return;
     }
     // Range guard.  An operand x with |x| >= 65520 splits into x1 = +-inf, x2 = x - x1 = -+inf, and every output of the
@@ -477,12 +487,21 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3b_kernel(const Fwd3
         for (int r = 0; r < 16; ++r) ss[(r >> 2) & 1] += x[t][r] * x[t][r];
 #pragma unroll
     for (int t = HT; t < NZT; ++t) l16_store_tile<HT>(t, x[t], a.z_out, sample, live, a.nz, a.half, g, a.vec4);
+#if LSNF_L16_PARTS == 2
+    // an operand at or beyond fp16's range (NaN compares false: it propagates by itself): this wave's results are not to
+    // be trusted -- its first logdet element carries the flag, the bf16x3 fix-up pass queued behind recomputes the workgroup
+    const bool wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0ull;
+#endif
     float ll[2];
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
         ll[st] = (-0.5f * l16_group_sum(ss[st]) + 1.8378770664093453f) + ell[st];
         if (live[st] && g == 0) {
-            a.logdet_out[sample[st]] = ell[st];
+            float ld = ell[st];
+#if LSNF_L16_PARTS == 2
+            if (wave_bad && st == 0 && n == 0) ld = __builtin_bit_cast(float, LSNF_F16_SENTINEL_BITS);
+#endif
+            a.logdet_out[sample[st]] = ld;
             if (a.ll_out) a.ll_out[sample[st]] = ll[st];
         }
     }
@@ -503,16 +522,6 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3b_kernel(const Fwd3
             lsnf_publish_stats(a.stats, tl, td, a.B);
         }
     }
-#if LSNF_L16_PARTS == 3
-    if (a.guard) {                                // fix-up pass done: the workgroup drawing the last ticket lowers the flag
-        __syncthreads();
-        if (tid == 0 && atomicAdd(&gslot[1], 1u) == gridDim.x - 1) { atomicExch(&gslot[0], 0u); atomicExch(&gslot[1], 0u); }
-    }
-#else
-    // an operand at or beyond fp16's range (NaN compares false: it propagates by itself): results of this launch are
-    // not to be trusted -- raise the flag, the bf16x3 fix-up pass queued behind this kernel recomputes every row
-    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) gslot[0] = a.guard_id;
-#endif
     F3_STAMP(41, "s_memtime");
     F3_STAMP(51, "s_memrealtime");
 }
@@ -546,14 +555,16 @@ hipError_t launch_fwd3(const Fwd3Args& a, hipStream_t stream) {
 hipError_t LSNF_FWD3_ENTRY(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                 const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                 float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
-                                int shape16, unsigned* guard, unsigned guard_id, hipStream_t stream) {
+                                int shape16, int fixup, hipStream_t stream) {
     Fwd3Args a;
     a.shape16 = shape16;
-    a.guard = guard; a.guard_id = guard_id;
+    a.fixup = fixup;
+    a.guard = reinterpret_cast<const unsigned*>(plan + g.off_guard);
 #if LSNF_L16_PARTS == 3
-    if (guard && !shape16) return hipErrorInvalidValue;      // the fix-up pass is the L16 kernel
+    if (fixup && !shape16) return hipErrorInvalidValue;      // the fix-up pass is the L16 kernel
+    if (fixup && stats) return hipErrorInvalidValue;         // (a partial recomputation cannot repair in-kernel batch sums)
 #else
-    if (!guard) return hipErrorInvalidValue;
+    if (stats) return hipErrorInvalidValue;                  // the fp16 forward is not used with in-kernel batch sums
 #endif
     a.stats = stats;
     a.act_saved = act_saved ? act_saved + (size_t)first_block * lsnf_act_layout(B, g.HT, g.WT).per_block : nullptr;

@@ -28,8 +28,13 @@
 // i.e. k-slot j of lane-half h in k-step s is accumulator register 8*s + j of that lane-half -- an output tile
 // converted to bf16 pairs in register order is directly the next GEMM's B operand.
 #define LSNF_FRAG3_FLOATS 1536 /* 2 k-steps x 3 parts x 1 KiB, in 4-byte units */
-#define LSNF_GUARD_WORDS 256
-#define LSNF_GUARD_SLOTS 127 /* (flag, ticket) pairs after word pair 0 */
+#define LSNF_GUARD_WORDS 256 /* word 0: folded weights outside fp16's range (written by lsnf_prepare only); rest reserved */
+// fp16 range guard (lsnf_fwd2h.hip / lsnf_rev2h.hip): a wave whose GEMMs met an operand outside fp16's range writes this
+// quiet-NaN bit pattern into the FIRST output element it owns (forward: logdet_out[first row of the wave]; reverse:
+// z_out[first row][0]) instead of the value; the bf16x3 fix-up pass queued behind the launch recomputes every workgroup
+// that finds the pattern in one of its waves' elements.  The flag lives in the launch's own output: launches in flight
+// on any number of streams (or replayed from any number of graphs) cannot see each other's.
+#define LSNF_F16_SENTINEL_BITS 0x7FD0F16Au
 #define LSNF_F16_GUARD_MAX 65504.0f /* |x| >= this does not survive the round-to-nearest fp16 conversion */
 #define LSNF_FRAG2H_FLOATS 1024 /* fp16 two-term split: 2 feature halves x 2 parts x 1 KiB */
 // The same three bf16 matrices once more in the A-operand order of v_mfma_f32_16x16x32_bf16 (lsnf_fwd3.hip, 16x16 variant;
@@ -67,9 +72,8 @@ struct LsnfGeo {
     size_t off_f2h_panels;
     int i2h_block_floats;       // inverse panel I1 likewise (lsnf_rev2h.hip)
     size_t off_i2h_panels;
-    size_t off_guard;           // LSNF_GUARD_WORDS 32-bit words of the fp16 range guard (lsnf_fwd2h.hip): [0] weights outside
-                                // fp16's range (set by prepare); then LSNF_GUARD_SLOTS pairs (flag, ticket): a forward
-                                // launch with id i uses pair 1 + i % SLOTS -- flag = i while its fix-up pass is due
+    size_t off_guard;           // LSNF_GUARD_WORDS 32-bit words; [0] = 1 if a folded weight is outside fp16's range (set by
+                                // lsnf_prepare, read-only afterwards): the fp16 kernels then leave every row to the fix-up pass
     size_t total_floats;
 };
 

@@ -25,7 +25,7 @@ struct Rev3Args {
     const float* fwd_consts; const float* inv_consts; const float* panels3b; const float* ipanels3b;
     const float* z_in; const float* objective; float* z_out; float* objective_out;
     int B, nz, half, depth, vec4;
-    unsigned* guard; unsigned guard_id;      // fp16 range guard, as in lsnf_fwd3.hip (Fwd3Args)
+    const unsigned* guard; int fixup;        // fp16 range guard, as in lsnf_fwd3.hip (Fwd3Args); the flag travels in z_out[first row of the wave][0]
 };
 
 template <class C, int NW>
@@ -38,13 +38,23 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_rev3_kernel(const Rev3Args a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int vec4 = a.vec4;
+    const long wbase = ((long)blockIdx.x * NW + wave) * 32;           // first row of this wave
 #if LSNF_L16_PARTS == 3
-    unsigned* const gslot = a.guard ? a.guard + 2 * (1 + a.guard_id % LSNF_GUARD_SLOTS) : nullptr;
-    if (gslot && gslot[0] != a.guard_id) return;  // fix-up pass of the fp16 reverse: nothing overflowed (kernel-uniform)
+    if (a.fixup) {                                // fix-up pass of the fp16 reverse: only workgroups in which a wave raised its flag
+        unsigned* fl = reinterpret_cast<unsigned*>(smem);
+        unsigned f = 0u;
+        if (wbase < a.B) f = __builtin_bit_cast(unsigned, a.z_out[wbase * (long)a.nz]) == LSNF_F16_SENTINEL_BITS ? 1u : 0u;
+        if (lane == 0) fl[wave] = f;
+        __syncthreads();
+        unsigned any = 0u;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) any |= fl[w];
+        __syncthreads();                          // (smem is reused below)
+        if (any == 0u) return;                    // workgroup-uniform
+    }
 #else
-    unsigned* const gslot = a.guard + 2 * (1 + a.guard_id % LSNF_GUARD_SLOTS);
-    if (a.guard[0] != 0u) {                       // weights outside fp16's range (prepare): leave everything to the fix-up pass
-        if (tid == 0) gslot[0] = a.guard_id;
+    if (a.guard[0] != 0u) {                       // weights outside fp16's range (prepare): leave every row to the fix-up pass
+        if (lane == 0 && wbase < a.B) a.z_out[wbase * (long)a.nz] = __builtin_bit_cast(float, LSNF_F16_SENTINEL_BITS);
         return;
     }
     bool bad = false;                             // an operand beyond fp16's range turns every output of its GEMM into NaN
@@ -139,6 +149,11 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_rev3_kernel(const Rev3Args a)
             for (int t = 0; t < NZT; ++t) x[t] = xn[t];
         }
     }
+#if LSNF_L16_PARTS == 2
+    // this wave met an operand beyond fp16's range: element [first row][0] of its output (register 0 of tile 0 on lane 0)
+    // carries the flag for the bf16x3 fix-up pass queued behind this kernel
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) x[0][0] = __builtin_bit_cast(float, LSNF_F16_SENTINEL_BITS);
+#endif
 #pragma unroll
     for (int t = 0; t < NZT; ++t) l16_store_tile<HT>(t, x[t], a.z_out, sample, live, a.nz, a.half, g, vec4);
     if (a.objective_out) {
@@ -146,14 +161,6 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_rev3_kernel(const Rev3Args a)
         for (int st = 0; st < 2; ++st)
             if (live[st] && g == 0) a.objective_out[sample[st]] = obj[st];
     }
-#if LSNF_L16_PARTS == 3
-    if (gslot) {                                  // fix-up pass done: the workgroup drawing the last ticket clears the slot
-        __syncthreads();
-        if (tid == 0 && atomicAdd(&gslot[1], 1u) == gridDim.x - 1) { atomicExch(&gslot[0], 0u); atomicExch(&gslot[1], 0u); }
-    }
-#else
-    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) gslot[0] = a.guard_id;
-#endif
 }
 
 template <class C, int NW>
@@ -178,14 +185,13 @@ hipError_t launch_rev3(const Rev3Args& a, hipStream_t stream) {
 #define LSNF_REV3_ENTRY lsnf_launch_reverse3
 #endif
 hipError_t LSNF_REV3_ENTRY(const LsnfGeo& g, const float* plan, int B, const float* z_in, const float* objective,
-                           float* z_out, float* objective_out, int vec4, unsigned* guard, unsigned guard_id, hipStream_t stream) {
+                           float* z_out, float* objective_out, int vec4, int fixup, hipStream_t stream) {
     Rev3Args a;
-    a.guard = guard; a.guard_id = guard_id;
+    a.guard = reinterpret_cast<const unsigned*>(plan + g.off_guard); a.fixup = fixup;
     a.fwd_consts = plan + g.off_fwd_const; a.inv_consts = plan + g.off_inv_const;
 #if LSNF_L16_PARTS == 3
     a.panels3b = plan + g.off_f3b_panels; a.ipanels3b = plan + g.off_i3b_panels;
 #else
-    if (!guard) return hipErrorInvalidValue;
     a.panels3b = plan + g.off_f2h_panels; a.ipanels3b = plan + g.off_i2h_panels;
 #endif
     a.z_in = z_in; a.objective = objective; a.z_out = z_out; a.objective_out = objective_out;

@@ -158,19 +158,25 @@ def forward(plan: FlowPlan, z: torch.Tensor, objective: Optional[torch.Tensor] =
     return z_out, logdet, ll, saved
 
 
+SMALL_BATCH_AUTO = -2
+
+
 def set_small_batch_max(rows: int) -> int:
-    """Batches <= rows use the small-batch (latency) kernels; returns the previous threshold (rows < 0: query)."""
+    """Batches <= rows use the small-batch (latency) kernels (one threshold for every entry point).  rows >= 0 sets it,
+    SMALL_BATCH_AUTO goes back to the built-in crossover of the arithmetic mode; both return the previous SETTING (a row
+    count or SMALL_BATCH_AUTO), so `prev = set(x); ...; set(prev)` restores exactly.  rows == -1 only queries the threshold
+    in force."""
     return _lib.load().lsnf_set_small_batch_max(int(rows))
 
 
-MATH_FP32, MATH_BF16X3, MATH_BF16X3_32, MATH_FP16X2 = 0, 1, 2, 3
+MATH_FP32, MATH_BF16X3, MATH_BF16X3_32, MATH_FP16X2, MATH_BF16X3_PIPE = 0, 1, 2, 3, 4
 
 
 def set_math_mode(mode: int) -> int:
-    """Arithmetic of the GEMMs (include/lsnf_flow.h): MATH_FP16X2 (default: throughput forward on a two-term fp16 split,
-    three fp16 MFMAs per product, range-guarded by a bf16x3 fix-up pass; everything else as MATH_BF16X3), MATH_BF16X3
-    (error-free three-way bf16 split, six bf16 MFMAs per product; 16x16x32 MFMA), MATH_BF16X3_32 (the same on the
-    32x32x16 MFMA, kept for comparison) or MATH_FP32 (fp32 MFMA).  All four are fp32-class in accuracy.
+    """Arithmetic of the GEMMs (include/lsnf_flow.h): MATH_BF16X3 (default: error-free three-way bf16 split, 24 operand
+    bits, six bf16 MFMAs per product; 16x16x32 MFMA), MATH_FP32 (fp32 MFMA), MATH_BF16X3_32 / MATH_BF16X3_PIPE (the
+    bf16x3 scheme on the 32x32x16 MFMA, phase-separated / software-pipelined: kept for comparison) or MATH_FP16X2
+    (opt-in, NARROWER than fp32: two-term fp16 split, three fp16 MFMAs per product, range-guarded by a bf16x3 fix-up pass).
     Returns the previous mode (mode < 0: query)."""
     return _lib.load().lsnf_set_math_mode(int(mode))
 

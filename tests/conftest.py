@@ -46,7 +46,7 @@ def gpu_device():
 
 
 @pytest.fixture(params=["latency-kernels", "latency-kernels-bf16x3", "throughput-kernels", "throughput-kernels-bf16x3",
-                        "throughput-kernels-bf16x3_32", "throughput-kernels-fp16x2"])
+                        "throughput-kernels-bf16x3_32", "throughput-kernels-bf16x3_pipe", "throughput-kernels-fp16x2"])
 def kernels(request):
     """Every parity test runs on both kernel families (normally selected by batch size, lsnf_set_small_batch_max) and,
     for the throughput family, with both arithmetic modes of the forward's GEMMs (lsnf_set_math_mode: fp32 MFMA, or
@@ -55,6 +55,7 @@ def kernels(request):
     prev = lsnf_amd.flow.set_small_batch_max(1 << 30 if request.param.startswith("latency-kernels") else 0)
     prev_math = lsnf_amd.flow.set_math_mode(lsnf_amd.flow.MATH_BF16X3 if request.param.endswith("bf16x3")
                                             else lsnf_amd.flow.MATH_BF16X3_32 if request.param.endswith("bf16x3_32")
+                                            else lsnf_amd.flow.MATH_BF16X3_PIPE if request.param.endswith("bf16x3_pipe")
                                             else lsnf_amd.flow.MATH_FP16X2 if request.param.endswith("fp16x2")
                                             else lsnf_amd.flow.MATH_FP32)
     yield request.param

@@ -164,7 +164,7 @@ def test_default_dispatch_mid_size_batch(lsnf, gpu_device):
     nz, width, depth, B = 100, 64, 5, 10000
     p = O.init_params(nz, width, depth, seed=5)
     plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
-    assert lsnf.flow.set_math_mode(-1) == lsnf.flow.MATH_FP16X2 and lsnf.flow.set_small_batch_max(-1) == 16384
+    assert lsnf.flow.set_math_mode(-1) == lsnf.flow.MATH_BF16X3 and lsnf.flow.set_small_batch_max(-1) == 16384
     z = torch.randn(B, nz, generator=torch.Generator().manual_seed(8))
     z1, ld, ll, saved, act = _fwd(lsnf, plan, z.to(gpu_device), True)
     g_stash = lsnf.backward_z(plan, z1, saved, ll_scale=-1.0, act_saved=act)
@@ -179,13 +179,13 @@ def test_default_dispatch_mid_size_batch(lsnf, gpu_device):
 
 
 def test_default_dispatch_large_batch(lsnf, gpu_device):
-    """Default dispatch at 40 000 rows: the fp16x2 throughput forward (lsnf_fwd2h.hip) writes z_saved and the activation
+    """Default dispatch at 40 000 rows: the bf16x3 throughput forward (lsnf_fwd3.hip) writes z_saved and the activation
     stash, the bf16x3 throughput backward (lsnf_bwd3.hip) reads them; the Langevin step built from the two matches the
     oracle on rows away from a ReLU kink."""
     nz, width, depth, B = 128, 64, 5, 40000
     p = O.init_params(nz, width, depth, seed=6)
     plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
-    assert lsnf.flow.set_math_mode(-1) == lsnf.flow.MATH_FP16X2
+    assert lsnf.flow.set_math_mode(-1) == lsnf.flow.MATH_BF16X3
     z = torch.randn(B, nz, generator=torch.Generator().manual_seed(9))
     z1, ld, ll, saved, act = _fwd(lsnf, plan, z.to(gpu_device), True)
     g_stash = lsnf.backward_z(plan, z1, saved, ll_scale=-1.0, act_saved=act)
@@ -202,8 +202,8 @@ def test_default_dispatch_large_batch(lsnf, gpu_device):
 
 def test_fp16_split_range_guard_reverse(lsnf, gpu_device):
     """The throughput reverse on the two-term fp16 split (lsnf_rev2h.hip) under the same range guard as the forward: a
-    row beyond fp16's range makes the bf16x3 pass behind it recompute the launch (bit-equal to LSNF_MATH_BF16X3), ordinary
-    launches keep the fp16 kernel's results, and those match the oracle."""
+    row beyond fp16's range makes the bf16x3 pass behind it recompute that row's workgroup (bit-equal to LSNF_MATH_BF16X3
+    there, the fp16 kernel's rows elsewhere), ordinary launches keep the fp16 kernel's results, and those match the oracle."""
     nz, width, depth, B = 128, 64, 5, 33000
     p = O.init_params(nz, width, depth, seed=31)
     plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
@@ -224,7 +224,10 @@ def test_fp16_split_range_guard_reverse(lsnf, gpu_device):
         # (the huge row itself may legitimately overflow fp32 in the reverse direction -- z2 / sigmoid(p) with p << 0 --
         # so compare bit patterns: whatever LSNF_MATH_BF16X3 returns, the guarded fp16 mode returns the same)
         bits = lambda t: t.view(torch.int32)
-        assert torch.equal(bits(got_big[0]), bits(ref_big[0])) and torch.equal(bits(got_big[1]), bits(ref_big[1]))
+        hot = slice(768, 1024)                                                   # the 256-row workgroup that holds row 777
+        cold = torch.ones(B, dtype=torch.bool, device=gpu_device); cold[hot] = False
+        assert torch.equal(bits(got_big[0][hot]), bits(ref_big[0][hot])) and torch.equal(bits(got_big[1][hot]), bits(ref_big[1][hot]))
+        assert torch.equal(got_big[0][cold], got[0][cold]) and torch.equal(got_big[1][cold], got[1][cold])
         keep = torch.ones(B, dtype=torch.bool, device=gpu_device); keep[777] = False
         assert torch.isfinite(got_big[0][keep]).all() and torch.isfinite(got_big[1][keep]).all()
         assert torch.equal(got[0], got2[0]) and torch.equal(got[1], got2[1])
@@ -237,3 +240,38 @@ def test_fp16_split_range_guard_reverse(lsnf, gpu_device):
     finally:
         lsnf.flow.set_math_mode(prev)
         lsnf.flow.set_small_batch_max(prev_small)
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "fp16x2"])
+def test_dispatch_window_between_the_two_crossovers(lsnf, gpu_device, mode):
+    """ADVICE r1: 12 288 < B <= 16 384 with the built-in thresholds.  Every entry point uses ONE threshold (16 384 rows;
+    12 288 in LSNF_MATH_FP16X2), so the family that writes z_saved / the activation stash is the family that reads them:
+    forward + stash, backward from the stash, recomputing backward and the Langevin step at B = 14 000 against the oracle.
+    Also: set(prev) restores the AUTO setting exactly (the old knob turned 'default' into 'set by the caller')."""
+    nz, width, depth, B = 100, 64, 5, 14000
+    p = O.init_params(nz, width, depth, seed=15)
+    plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
+    before = lsnf.flow.set_small_batch_max(lsnf.flow.SMALL_BATCH_AUTO)
+    assert lsnf.flow.set_small_batch_max(4096) == lsnf.flow.SMALL_BATCH_AUTO       # the previous SETTING comes back, not a row count
+    assert lsnf.flow.set_small_batch_max(lsnf.flow.SMALL_BATCH_AUTO) == 4096       # ... and AUTO again
+    prev = lsnf.flow.set_math_mode(lsnf.flow.MATH_FP16X2 if mode == "fp16x2" else lsnf.flow.MATH_BF16X3)
+    try:
+        assert lsnf.flow.set_small_batch_max(-1) == (12288 if mode == "fp16x2" else 16384)
+        z = torch.randn(B, nz, generator=torch.Generator().manual_seed(16))
+        z1, ld, ll, saved, act = _fwd(lsnf, plan, z.to(gpu_device), True)
+        g_stash = lsnf.backward_z(plan, z1, saved, ll_scale=-1.0, act_saved=act)
+        g_rec = lsnf.backward_z(plan, z1, saved, ll_scale=-1.0)
+        idx = torch.arange(7, B, 131)
+        ref = O.grad_neg_sum_ll_wrt_z(p, z[idx])
+        ok = O.relu_margin(p, z[idx]) > KINK
+        for g in (g_stash, g_rec):
+            assert ((g.cpu()[idx] - ref)[ok].norm() / ref[ok].norm()).item() <= 1e-5
+        _, _, llr = O.flow_log_prob(p, z[idx])
+        assert ((ll.cpu()[idx] - llr).abs() / llr.abs()).max().item() <= 1e-5
+        zn, ll2, _, _ = lsnf.langevin_step(plan, z.to(gpu_device), None, None, 0.1)
+        zr = z[idx].double() - 0.005 * ref.double()
+        assert ((zn.cpu()[idx].double() - zr)[ok].abs().max() / zr.abs().max()).item() <= 2e-5
+        assert torch.equal(ll2, ll)
+    finally:
+        lsnf.flow.set_math_mode(prev)
+        lsnf.flow.set_small_batch_max(before)
