@@ -32,7 +32,7 @@ def hps_for(width, depth=5, coupling=1):
                                  f_width=width, f_flow_coupling=coupling)
 
 
-def build_netF(nz, width, seed, fcz_std, all_std, depth=5, coupling=1):
+def build_netF(nz, width, seed, fcz_std, all_std, depth=5, coupling=1, matrix_fan_in_scaled=False):
     """Reference init under fixed seeds (W init uses numpy QR, model.py:176), then the
     perturbations SURVEY 8c prescribes so that the coupling is non-trivial."""
     torch.manual_seed(seed)
@@ -49,7 +49,10 @@ def build_netF(nz, width, seed, fcz_std, all_std, depth=5, coupling=1):
                     continue
                 if name.endswith("fc_1.b") or name.endswith("fc_2.b"):
                     continue
-                prm.add_(torch.randn(prm.shape, generator=g) * all_std)
+                std = all_std
+                if matrix_fan_in_scaled and prm.dim() == 2 and prm.shape[0] > 1:
+                    std = all_std / np.sqrt(prm.shape[0])      # an O(all_std) perturbation of the OPERATOR, not of every entry
+                prm.add_(torch.randn(prm.shape, generator=g) * std)
     return net
 
 
@@ -59,8 +62,9 @@ def ll_of(z1, logdet):
     return prior_ll + logdet                                        # train.py:319
 
 
-def run_case(name, nz, width, B, sigma_z, seed, fcz_std=0.05, all_std=0.0, with_param_grads=True, coupling=1):
-    net = build_netF(nz, width, seed, fcz_std, all_std, coupling=coupling)
+def run_case(name, nz, width, B, sigma_z, seed, fcz_std=0.05, all_std=0.0, with_param_grads=True, coupling=1,
+             matrix_fan_in_scaled=False):
+    net = build_netF(nz, width, seed, fcz_std, all_std, coupling=coupling, matrix_fan_in_scaled=matrix_fan_in_scaled)
     g = torch.Generator().manual_seed(seed + 77)
     z = (sigma_z * torch.randn(B, nz, generator=g)).float()
     obj0 = torch.zeros(B)
@@ -110,7 +114,7 @@ def run_case(name, nz, width, B, sigma_z, seed, fcz_std=0.05, all_std=0.0, with_
         out["block_logdet"] = np.stack(ls)
 
     # fp64 tie-breaker: the same module in double
-    net64 = build_netF(nz, width, seed, fcz_std, all_std, coupling=coupling).double()
+    net64 = build_netF(nz, width, seed, fcz_std, all_std, coupling=coupling, matrix_fan_in_scaled=matrix_fan_in_scaled).double()
     with torch.no_grad():
         z1d, ldd, _ = net64(z.double(), objective=torch.zeros(B, dtype=torch.float64))
         out["ll_f64"] = ll_of(z1d, ldd).numpy().copy()
@@ -233,6 +237,19 @@ def affine_cases():
     run_langevin("langevin_nz100_w64_B16_K3")
 
 
+def trained02_cases():
+    # SURVEY 8c's second variant ("trained-like": 0.3 * randn on all parameters, to stress the exp / sigmoid tails) at the
+    # headline geometry (C3) and the CelebA-HQ one (C5, f_width 128), odd batch sizes -- at the strongest setting for which
+    # the REFERENCE still returns numbers.  Scanned with this script's build_netF (seed 41, 65 rows):
+    #   0.3 on every entry, or 0.3 on vectors + 0.3/sqrt(fan_in) on matrices : ll = -inf on the rows that matter, |z1| up to
+    #        1e15 resp. 1.5e3, reverse(forward(z)) = NaN -- the reference's log(sigmoid(.)) underflows: no parity information
+    #   0.2 on vectors (every actnorm b / logs, fc_zeros b / logs: exp(3 logs) spans e^-1.8 .. e^+1.8 at 3 sigma) and
+    #   0.2/sqrt(fan_in) on matrices (an O(0.2) perturbation of each operator): ll in [-9e3, -8e2], |z1| up to 40, the
+    #        reference's own fp32-vs-fp64 log-prob noise 7e-7, its own round trip 1.4e-3 -- finite, and far outside init
+    run_case("c3_nz128_w64_B65_trained02", 128, 64, 65, 1.0, seed=41, fcz_std=0.0, all_std=0.2, matrix_fan_in_scaled=True)
+    run_case("c5_nz100_w128_B33_trained02", 100, 128, 33, 1.0, seed=42, fcz_std=0.0, all_std=0.2, matrix_fan_in_scaled=True)
+
+
 def additive_cases():
     # additive coupling, f_flow_coupling=0 (model.py:385,407-408,429-430)
     run_case("additive_nz20_w12_B33", 20, 12, 33, 1.0, seed=21, coupling=0)
@@ -240,10 +257,12 @@ def additive_cases():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["affine", "additive"]      # `make_golden.py additive` rewrites only that group
+    which = sys.argv[1:] or ["affine", "additive", "trained02"]      # `make_golden.py additive` rewrites only that group
     if "affine" in which:
         affine_cases()
     if "additive" in which:
         additive_cases()
+    if "trained02" in which:
+        trained02_cases()
     if "netg" in which:
         netg_cases()

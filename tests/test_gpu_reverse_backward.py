@@ -36,6 +36,16 @@ def _plan(lsnf, p, g, dev):
     return lsnf.prepare(lsnf.params_from_state_dict(p, d, dev), nz, w, d, int(g.get("meta_coupling", 1)))
 
 
+def inverse_tolerance(g, floor):
+    """Tolerance of an inverse-pass comparison, relative to the data's scale: `floor` (what a well-conditioned flow
+    achieves: the fuzz sweep holds the reverse to 5e-5, tools/fuzz_parity.py), or 3x the REFERENCE's own fp32 round-trip
+    error reverse(forward(z)) - z stored in the fixture, whichever is larger -- the inverse of an ill-conditioned stack
+    (the trained-like fixtures: reference round trip 1.4e-3) amplifies fp32 rounding in any implementation."""
+    zmax = max(1.0, float(np.abs(g["z"]).max()))
+    own = float(np.abs(g["roundtrip"] - g["z"]).max()) / zmax
+    return max(floor, 3.0 * own)
+
+
 @pytest.mark.parametrize("name", golden_names())
 def test_reverse_matches_reference_golden(lsnf, kernels, gpu_device, name):
     p, g = load_golden(name)
@@ -43,7 +53,7 @@ def test_reverse_matches_reference_golden(lsnf, kernels, gpu_device, name):
     x, obj = lsnf.reverse(plan, torch.from_numpy(g["rev_in"]).to(gpu_device))
     x, negobj = x.cpu().numpy(), -obj.cpu().numpy()          # reference returns -objective (model.py:498)
     scale = max(1.0, np.abs(g["rev_out"]).max())
-    assert np.max(np.abs(x - g["rev_out"])) <= 5e-4 * scale
+    assert np.max(np.abs(x - g["rev_out"])) <= inverse_tolerance(g, 5e-5) * scale
     assert np.max(np.abs(negobj - g["rev_negobj"]) / np.maximum(np.abs(g["rev_negobj"]), 1.0)) <= 1e-5
 
 
@@ -56,7 +66,7 @@ def test_roundtrip_forward_reverse(lsnf, kernels, gpu_device, name):
     z1, ld, _, _ = lsnf.forward(plan, z)
     back, obj = lsnf.reverse(plan, z1, ld)
     zmax = max(1.0, z.abs().max().item())
-    assert (back - z).abs().max().item() <= 2e-3 * zmax
+    assert (back - z).abs().max().item() <= inverse_tolerance(g, 1e-4) * zmax
     assert (obj.abs() / ld.abs().clamp_min(1.0)).max().item() <= 2e-5
 
 

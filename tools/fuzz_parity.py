@@ -34,7 +34,7 @@ def run(n_cases, seed, batches=BATCHES):
     checks = 0
     rs = np.random.RandomState(seed)
     t00 = time.time()
-    prev_small, prev_mode = flow.set_small_batch_max(-1), flow.set_math_mode(-1)
+    prev_small, prev_mode = flow.set_small_batch_max(flow.SMALL_BATCH_AUTO), flow.set_math_mode(-1)   # (restored below)
     try:
         for case in range(n_cases):
             nz = 2 * int(rs.randint(1, 65))
