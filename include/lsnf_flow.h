@@ -141,6 +141,11 @@ int lsnf_prepare(const float* const* params_host, int nz, int width, int depth, 
  *             what autograd would keep besides the block outputs (the coupling's sigmoid and the two
  *             relu masks, model.py:307-308,415), indexed by absolute block.  Handing it to
  *             lsnf_backward_z / lsnf_langevin_step removes their recomputation of the coupling MLP.
+ *   params_workspace NULL, or the workspace of the lsnf_backward_params call that will follow for this evaluation
+ *             (lsnf_backward_params_workspace_floats(), 16-byte aligned): the forward then also writes the hidden
+ *             activations h1, h2 of every block into it, which lets lsnf_backward_params run FROM THE STASH instead of
+ *             recomputing the coupling MLP.  Whole stack only, with act_saved and z_saved; needs a bf16x3-family math
+ *             mode (lsnf_params_fast_path() == 1, LSNF_E_ARG otherwise).
  *   stats     NULL, or 8 doubles (device, 8-byte aligned) that the caller zero-initialises ONCE:
  *             after the launch stats[4] = sum_b ll_b (train.py:320), stats[5] = sum_b logdet_b,
  *             stats[6] = B.  Summed inside the kernel (fp64 atomics, one pair per workgroup; the last
@@ -150,7 +155,7 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling,
                  int first_block, int n_blocks, int B,
                  const float* z_in, const float* objective,
                  float* z_out, float* logdet_out, float* ll_out, float* z_saved,
-                 float* act_saved, double* stats, void* stream);
+                 float* act_saved, float* params_workspace, double* stats, void* stream);
 
 /* floats of lsnf_forward's optional activation stash for a batch of B rows (0 on bad geometry) */
 size_t lsnf_act_saved_floats(int nz, int width, int depth, int B);
@@ -211,13 +216,20 @@ int lsnf_langevin_step(const float* plan, int nz, int width, int depth, int coup
  *   grads_host  : HOST array of depth*12 DEVICE pointers that receive the gradients (a NULL entry
  *                 skips that tensor); shapes as the parameters
  *   z_in        : (B, nz) input of the stack; z_out / z_saved as written by lsnf_forward
+ *   act_saved   : NULL -- the backward recomputes the coupling MLP (fp32 MFMA) -- or the stash of the lsnf_forward call of
+ *                 this evaluation, which must then ALSO have been given `params_workspace` = this call's `workspace`
+ *                 (fast path: backward from the stash on the bf16 matrix pipe, nothing recomputed; same math mode and
+ *                 small-batch threshold in force for both calls; ignored when lsnf_params_fast_path() == 0)
  *   g_z_in      : NULL, or (B, nz) to also receive dL/dz_in (same values as lsnf_backward_z)
  *   workspace   : lsnf_backward_params_workspace_floats() floats, 16-byte aligned.
- * Sums over the batch use fp32 atomics when B > 1024 (order, hence last bits, may vary run to run). */
+ * Sums over the batch use fp32 atomics when B > 1024 (order, hence last bits, may vary run to run:
+ * tests/test_gpu_module.py bounds the spread at B = 65 536 to 2e-6 of each tensor's norm). */
 size_t lsnf_backward_params_workspace_floats(int nz, int width, int depth, int B);
+/* 1 if the math mode in force offers the from-the-stash fast path of lsnf_backward_params (every bf16x3-family mode) */
+int lsnf_params_fast_path(void);
 int lsnf_backward_params(const float* plan, const float* const* params_host, float* const* grads_host,
                          int nz, int width, int depth, int coupling, int B,
-                         const float* z_in, const float* z_out, const float* z_saved,
+                         const float* z_in, const float* z_out, const float* z_saved, const float* act_saved,
                          const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
                          float* g_z_in, float* workspace, void* stream);
 

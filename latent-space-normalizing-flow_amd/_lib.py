@@ -31,7 +31,8 @@ _SIGNATURES = {
     "lsnf_prepare_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
     "lsnf_prepare": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "lsnf_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lsnf_params_fast_path": (c_int, []),
     "lsnf_act_saved_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "lsnf_reverse": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int,
                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -43,7 +44,7 @@ _SIGNATURES = {
     "lsnf_backward_params_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "lsnf_backward_params": (c_int, [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
                                      c_int, c_int, c_int, c_int, c_int,
-                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                      c_void_p, c_void_p, c_void_p]),
 }
 

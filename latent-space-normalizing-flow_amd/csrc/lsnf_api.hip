@@ -25,18 +25,18 @@ hipError_t lsnf_launch_forward(const LsnfGeo& g, const float* plan, int first_bl
 hipError_t lsnf_launch_forward3(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                 const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                 float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
-                                int shape16, int fixup, hipStream_t stream);
+                                int shape16, int fixup, hipStream_t stream, float* hdump = nullptr);
 hipError_t lsnf_launch_forward3p(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                  const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                  float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4, hipStream_t stream);
 hipError_t lsnf_launch_forward2h(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                  const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                  float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
-                                 int shape16, int fixup, hipStream_t stream);
+                                 int shape16, int fixup, hipStream_t stream, float* hdump = nullptr);
 hipError_t lsnf_launch_small3_forward(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                       const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                       float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
-                                      hipStream_t stream);
+                                      hipStream_t stream, float* hdump = nullptr);
 hipError_t lsnf_launch_small_forward(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                      const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                      float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
@@ -61,15 +61,17 @@ hipError_t lsnf_launch_small_backward_z(const LsnfGeo& g, const float* plan, int
                                         float* dump = nullptr, float* gl_total = nullptr);
 hipError_t lsnf_launch_small3_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
                                          const float* act_saved, const float* g_z1, const float* g_logdet, int ll_mode,
-                                         float ll_scale, float* g_z_in, int vec4, hipStream_t stream, const LsnfLangevinArgs* lv);
+                                         float ll_scale, float* g_z_in, int vec4, hipStream_t stream, const LsnfLangevinArgs* lv,
+                                         float* dump = nullptr, float* gl_total = nullptr);
 hipError_t lsnf_launch_backward3_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
                                    const float* act_saved, const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
-                                   float* g_z_in, int vec4, hipStream_t stream, const LsnfLangevinArgs* lv);
+                                   float* g_z_in, int vec4, hipStream_t stream, const LsnfLangevinArgs* lv,
+                                   float* dump = nullptr, float* gl_total = nullptr);
 hipError_t lsnf_launch_backward_params(const LsnfGeo& g, const float* plan, const float* const* params_host,
                                        float* const* grads_host, int B, const float* z_in, const float* z_out,
                                        const float* z_saved, const float* g_z1, const float* g_logdet, int ll_mode,
                                        float ll_scale, float* g_z_in, float* workspace, int vec4, int small_batch,
-                                       hipStream_t stream);
+                                       hipStream_t stream, const float* act_saved);
 
 namespace {
 thread_local char g_err[512] = "";
@@ -205,9 +207,11 @@ int lsnf_prepare(const float* const* params_host, int nz, int width, int depth, 
     return LSNF_OK;
 }
 
+int lsnf_params_fast_path(void) { return l16_math() ? 1 : 0; }
+
 int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, int first_block, int n_blocks, int B,
                  const float* z_in, const float* objective, float* z_out, float* logdet_out, float* ll_out,
-                 float* z_saved, float* act_saved, double* stats, void* stream) {
+                 float* z_saved, float* act_saved, float* params_workspace, double* stats, void* stream) {
     LsnfGeo g;
     if (int rc = geo_or_fail(&g, nz, width, depth, coupling)) return rc;
     if (B < 0 || B > (1 << 28)) return fail(LSNF_E_ARG, "lsnf_forward: B=%d out of range", B);
@@ -226,6 +230,14 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
     const int vec4 = row_vector_width(g, {z_in, z_out, z_saved});
     if (act_saved && !aligned16(act_saved)) return fail(LSNF_E_ARG, "lsnf_forward: act_saved must be 16-byte aligned");
     if (stats && (reinterpret_cast<uintptr_t>(stats) & 7u)) return fail(LSNF_E_ARG, "lsnf_forward: stats must be 8-byte aligned");
+    float* hdump = nullptr;              // h1 / h2 of every block into the parameter-gradient workspace (lsnf_backward_params' fast path)
+    if (params_workspace) {
+        if (!l16_math()) return fail(LSNF_E_ARG, "lsnf_forward: params_workspace needs a bf16x3-family math mode (lsnf_params_fast_path() == 1)");
+        if (first_block != 0 || n_blocks != depth || !act_saved || (depth > 1 && !z_saved))
+            return fail(LSNF_E_ARG, "lsnf_forward: params_workspace goes with the whole stack, act_saved and z_saved");
+        if (!aligned16(params_workspace)) return fail(LSNF_E_ARG, "lsnf_forward: params_workspace must be 16-byte aligned");
+        hdump = params_workspace + 4 + (size_t)depth * lsnf_fold_layout(nz, width).per_block;
+    }
     // batch-size dispatch: latency kernel (32 rows per workgroup, stages split over the 4 waves) below the
     // crossover, throughput kernel (128 rows per workgroup, weights shared through LDS) above it
     hipError_t e;
@@ -235,8 +247,8 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
         e = hipErrorInvalidValue;
         if (l16_math())                           // latency forward on the bf16 pipe: 16-sample workgroups (lsnf_small3_fwd.hip)
             e = lsnf_launch_small3_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
-                                           z_saved, act_saved, stats, vec4, (hipStream_t)stream);
-        if (e == hipErrorInvalidValue)
+                                           z_saved, act_saved, stats, vec4, (hipStream_t)stream, hdump);
+        if (e == hipErrorInvalidValue && !hdump)
             e = lsnf_launch_small_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
                                           z_saved, act_saved, stats, vec4, (hipStream_t)stream);
     } else {
@@ -249,18 +261,18 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
                              (objective == nullptr || objective != logdet_out);
         if (fp16_ok) {
             e = lsnf_launch_forward2h(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
-                                      z_saved, act_saved, nullptr, vec4, 1, 0, (hipStream_t)stream);
+                                      z_saved, act_saved, nullptr, vec4, 1, 0, (hipStream_t)stream, hdump);
             if (e == hipSuccess)
                 e = lsnf_launch_forward3(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
-                                         z_saved, act_saved, nullptr, vec4, 1, /*fixup=*/1, (hipStream_t)stream);
+                                         z_saved, act_saved, nullptr, vec4, 1, /*fixup=*/1, (hipStream_t)stream, hdump);
         }
-        if (math == LSNF_MATH_BF16X3_PIPE)        // the 32x32x16 kernel with its vector work pipelined under the MFMAs (lsnf_fwd3p.hip)
+        if (math == LSNF_MATH_BF16X3_PIPE && !hdump)   // the 32x32x16 kernel with its vector work pipelined under the MFMAs (lsnf_fwd3p.hip)
             e = lsnf_launch_forward3p(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
                                       z_saved, act_saved, stats, vec4, (hipStream_t)stream);
         if (e == hipErrorInvalidValue && (split || math == LSNF_MATH_FP16X2))   // error-free split on the bf16 matrix pipe (lsnf_fwd3.hip)
             e = lsnf_launch_forward3(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
-                                     z_saved, act_saved, stats, vec4, math != LSNF_MATH_BF16X3_32, /*fixup=*/0, (hipStream_t)stream);
-        if (e == hipErrorInvalidValue)            // fp32 MFMA kernel (also: stacks too deep for fwd3's LDS budget)
+                                     z_saved, act_saved, stats, vec4, math != LSNF_MATH_BF16X3_32, /*fixup=*/0, (hipStream_t)stream, hdump);
+        if (e == hipErrorInvalidValue && !hdump)  // fp32 MFMA kernel (also: stacks too deep for fwd3's LDS budget)
             e = lsnf_launch_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
                                     z_saved, act_saved, stats, vec4, (hipStream_t)stream);
     }
@@ -385,8 +397,8 @@ size_t lsnf_backward_params_workspace_floats(int nz, int width, int depth, int B
 
 int lsnf_backward_params(const float* plan, const float* const* params_host, float* const* grads_host, int nz, int width,
                          int depth, int coupling, int B, const float* z_in, const float* z_out, const float* z_saved,
-                         const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale, float* g_z_in,
-                         float* workspace, void* stream) {
+                         const float* act_saved, const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
+                         float* g_z_in, float* workspace, void* stream) {
     LsnfGeo g;
     if (int rc = geo_or_fail(&g, nz, width, depth, coupling)) return rc;
     if (B < 1 || B > (1 << 28)) return fail(LSNF_E_ARG, "lsnf_backward_params: B=%d out of range", B);
@@ -400,9 +412,10 @@ int lsnf_backward_params(const float* plan, const float* const* params_host, flo
     if (!aligned4(z_in) || !aligned4(z_out) || !aligned4(z_saved) || !aligned4(g_z1) || !aligned4(g_logdet) || !aligned4(g_z_in))
         return fail(LSNF_E_ARG, "lsnf_backward_params: tensors must be 4-byte aligned");
     const int vec4 = row_vector_width(g, {z_out, g_z_in, z_saved, g_z1});
+    if (act_saved && !aligned16(act_saved)) return fail(LSNF_E_ARG, "lsnf_backward_params: act_saved must be 16-byte aligned");
     hipError_t e = lsnf_launch_backward_params(g, plan, params_host, grads_host, B, z_in, z_out, z_saved, g_z1, g_logdet,
                                                ll_mode, ll_scale, g_z_in, workspace, vec4, B <= small_batch_max(),
-                                               (hipStream_t)stream);
+                                               (hipStream_t)stream, l16_math() ? act_saved : nullptr);
     if (e != hipSuccess) return hip_fail(e, "lsnf_backward_params launch");
     return LSNF_OK;
 }

@@ -6,6 +6,7 @@
 //   B2 : g_v1 = g_x1 + W1' g_a1                          B1 : g_x  = Wa [g_v1; g_v2]
 // Transposed matrices as bf16x3 panels in the 16x16x32 operand order (plan region off_b3b_panels), streamed L2 -> LDS in
 // panel pairs as in the forward.
+#include <stdlib.h>
 #include "lsnf_l16.h"
 
 namespace {
@@ -31,6 +32,8 @@ struct Bwd3Args {
     float step, ll_scale;
     LsnfRngArgs rng;
     int ll_mode, B, nz, half, depth, vec4;
+    float* dump; float* gl_total; int width;      // DUMP variant (parameter gradients, lsnf_params.hip): per block g_v, g_a1, g_a2,
+                                                  // g_t, g_p written for the batch contraction; G = sum_b dL/dlogdet_b
 };
 
 // stash -> L16 registers (inverse of l16_store_sigma / l16_store_masks)
@@ -58,7 +61,7 @@ __device__ __forceinline__ unsigned l16_load_mask(const unsigned* words, int n, 
     return m;
 }
 
-template <class C, int NW>
+template <class C, int NW, bool DUMP>
 __global__ __launch_bounds__(64 * NW, 1) void lsnf_bwd3_kernel(const Bwd3Args a) {
     constexpr int HT = C::HT, WT = C::WT, NZT = C::NZT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -100,6 +103,16 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_bwd3_kernel(const Bwd3Args a)
     }
     auto zero = [](int) { return lsnf_zero16(); };
     auto keep = [](f32x16 acc, int) { return acc; };
+    const LsnfDumpLayout dl = lsnf_dump_layout(a.B, a.nz, a.width);
+    const bool w4 = (a.width & 3) == 0, h4 = (a.half & 3) == 0;
+    if constexpr (DUMP) {   // G = sum_b dL/dlogdet_b: one atomic per wave
+        float t = 0.0f;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) t += (live[st] && g == 0) ? gl[st] : 0.0f;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        if (lane == 0) atomicAdd(a.gl_total, t);
+    }
 
     for (int blk = last; blk >= 0; --blk) {
         const float* gb = a.panels + (size_t)blk * C::BLOCKB;
@@ -124,6 +137,14 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_bwd3_kernel(const Bwd3Args a)
                 tp[HT + t][r] = (1.0f - sg[r]) * (gy2 * y2[r] + gl[(r >> 2) & 1]);
             }
         }
+        float* dmp = DUMP ? a.dump + (size_t)blk * dl.per_block : nullptr;
+        if constexpr (DUMP) {
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+                l16_store_plain(tp[t], dmp + dl.off_gt, sample, live, a.half, t, g, h4);
+                l16_store_plain(tp[HT + t], dmp + dl.off_gp, sample, live, a.half, t, g, h4);
+            }
+        }
         // ---- B4: g_a2 = ([W3s W3p][g_t; g_p]) gated by h2 > 0 ----
         f32x16 gh2[WT];
         {
@@ -133,6 +154,10 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_bwd3_kernel(const Bwd3Args a)
         }
 #pragma unroll
         for (int t = 0; t < WT; ++t) gh2[t] = lsnf_apply_mask16(gh2[t], m2[t]);
+        if constexpr (DUMP) {
+#pragma unroll
+            for (int t = 0; t < WT; ++t) l16_store_plain(gh2[t], dmp + dl.off_ga2, sample, live, a.width, t, g, w4);
+        }
         // ---- B3: g_a1 = (W2' g_a2) gated by h1 > 0 ----
         f32x16 gh1[WT];
         {
@@ -142,6 +167,10 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_bwd3_kernel(const Bwd3Args a)
         }
 #pragma unroll
         for (int t = 0; t < WT; ++t) gh1[t] = lsnf_apply_mask16(gh1[t], m1[t]);
+        if constexpr (DUMP) {
+#pragma unroll
+            for (int t = 0; t < WT; ++t) l16_store_plain(gh1[t], dmp + dl.off_ga1, sample, live, a.width, t, g, w4);
+        }
         // ---- B2: g_v1 = g_x1 (direct) + W1' g_a1 ;  gv = [g_v1 ; g_v2] ----
         f32x16 gv[NZT];
         {
@@ -152,6 +181,10 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_bwd3_kernel(const Bwd3Args a)
         }
 #pragma unroll
         for (int t = 0; t < HT; ++t) gv[HT + t] = tp[t];
+        if constexpr (DUMP) {
+#pragma unroll
+            for (int t = 0; t < NZT; ++t) l16_store_tile<HT>(t, gv[t], dmp + dl.off_gv, sample, live, a.nz, a.half, g, vec4);
+        }
         // ---- B1: g_x = Wa [g_v1; g_v2] ----
         {
             Split3 vs[2 * NZT];
@@ -223,25 +256,29 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_bwd3_kernel(const Bwd3Args a)
 template <class C, int NW>
 hipError_t launch_bwd3_w(const Bwd3Args& a, hipStream_t stream) {
     const size_t lds = 2 * (size_t)C::SLOT3 * sizeof(float);
-    auto kern = lsnf_bwd3_kernel<C, NW>;
-    static unsigned long long lds_ok = 0;
-    if (hipError_t e = lsnf_allow_big_lds((const void*)kern, &lds_ok); e != hipSuccess) return e;
+    auto kern = a.dump ? lsnf_bwd3_kernel<C, NW, true> : lsnf_bwd3_kernel<C, NW, false>;
+    static unsigned long long lds_ok[2] = {0, 0};
+    if (hipError_t e = lsnf_allow_big_lds((const void*)kern, &lds_ok[a.dump ? 1 : 0]); e != hipSuccess) return e;
     const unsigned grid = (unsigned)((a.B + 32 * NW - 1) / (32 * NW));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, a);
     return hipGetLastError();
 }
 template <class C>
 hipError_t launch_bwd3(const Bwd3Args& a, hipStream_t stream) {
-    return a.B > 128 * 256 ? launch_bwd3_w<C, 8>(a, stream) : launch_bwd3_w<C, 4>(a, stream);
+    static const char* fw = getenv("LSNF_FORCE_WAVES");   // experiment knob (tools/): 4 or 8
+    const bool eight = fw ? atoi(fw) == 8 : a.B > 128 * 256;
+    return eight ? launch_bwd3_w<C, 8>(a, stream) : launch_bwd3_w<C, 4>(a, stream);
 }
 }  // namespace
 
 // host-side dispatcher (called from lsnf_api.hip); needs the activation stash; hipErrorInvalidValue = not covered
 hipError_t lsnf_launch_backward3_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
                                    const float* act_saved, const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
-                                   float* g_z_in, int vec4, hipStream_t stream, const LsnfLangevinArgs* lv) {
+                                   float* g_z_in, int vec4, hipStream_t stream, const LsnfLangevinArgs* lv,
+                                   float* dump, float* gl_total) {
     if (!act_saved) return hipErrorInvalidValue;
     Bwd3Args a;
+    a.dump = dump; a.gl_total = gl_total; a.width = g.width;
     a.panels = plan + g.off_b3b_panels;
     a.z_out = z_out; a.z_saved = z_saved; a.act_saved = act_saved; a.g_z1 = g_z1; a.g_logdet = g_logdet; a.g_z_in = g_z_in;
     a.z_cur = nullptr; a.grad_g = nullptr; a.noise = nullptr; a.z_new = nullptr; a.gf_norm = nullptr; a.gg_norm = nullptr; a.step = 0.f;

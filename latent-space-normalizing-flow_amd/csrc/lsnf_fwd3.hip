@@ -18,6 +18,7 @@
 // 32 768 rows) or 4 waves, wave = 32 samples; weights stream L2 -> LDS by LDS-DMA in panel pairs exactly as in lsnf_fwd.hip.  Because the k-slot j of
 // lane-half h in k-step s is accumulator register 8*s + j (lsnf_layout.h), an output tile converted to bf16 pairs in
 // register order is directly the next GEMM's B operand.
+#include <stdlib.h>
 #include "lsnf_l16.h"
 
 namespace {
@@ -45,6 +46,7 @@ struct Fwd3Args {
     unsigned long long* stamps;        // LSNF_STAMPS diagnostic build only: [waves & 2047][64] clock stamps
     int shape16;                       // 1: the v_mfma_f32_16x16x32_bf16 variant (panels3 then points at its operand order)
     const unsigned* guard;             // fp16x2 kernel: the plan's guard words ([0]: weights outside fp16's range), read only
+    float* hdump; int width;           // L16 kernels: NULL, or the parameter-gradient dump (LsnfDumpLayout): h1, h2 of every block
     int fixup;                         // bf16x3 L16 kernel: 1 = run as the fix-up pass of an fp16x2 launch: a workgroup
                                        // recomputes its rows only if one of its waves left LSNF_F16_SENTINEL_BITS in
                                        // logdet_out (lsnf_layout.h); the flag travels in the launch's own output
@@ -389,6 +391,8 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3b_kernel(const Fwd3
     for (int st = 0; st < 2; ++st) ell[st] = a.objective ? a.objective[rows[st]] : 0.0f;
 
     const LsnfActLayout al = lsnf_act_layout(a.B, HT, WT);
+    const LsnfDumpLayout dl = lsnf_dump_layout(a.B, a.nz, a.width);
+    const bool w4 = (a.width & 3) == 0;
     const size_t wtile = (size_t)blockIdx.x * F3_WAVES + wave;
     for (int blk = 0; blk < a.n_blocks; ++blk) {
         float* act = (a.act_saved && wtile * 32 < (size_t)a.B)
@@ -432,6 +436,10 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3b_kernel(const Fwd3
 #pragma unroll
             for (int t = 0; t < WT; ++t) l16_store_masks(reinterpret_cast<unsigned*>(act + al.mask_off) + t * 64, h1[t], n, g);
         }
+        if (a.hdump) {           // kernel-uniform: h1 for the batch contraction dW2' = h1^T g_a2 (lsnf_params.hip)
+#pragma unroll
+            for (int t = 0; t < WT; ++t) l16_store_plain(h1[t], a.hdump + (size_t)blk * dl.per_block + dl.off_h1, sample, live, a.width, t, g, w4);
+        }
         // ---- S3: h2 = relu(actnorm(h1 @ W2))  (model.py:326-328,308) ----
         f32x16 h2[WT];
         {
@@ -444,6 +452,10 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3b_kernel(const Fwd3
         if (act) {
 #pragma unroll
             for (int t = 0; t < WT; ++t) l16_store_masks(reinterpret_cast<unsigned*>(act + al.mask_off) + (WT + t) * 64, h2[t], n, g);
+        }
+        if (a.hdump) {
+#pragma unroll
+            for (int t = 0; t < WT; ++t) l16_store_plain(h2[t], a.hdump + (size_t)blk * dl.per_block + dl.off_h2, sample, live, a.width, t, g, w4);
         }
         // ---- S4: shift t / pre-sigmoid p = fc_zeros(h2), de-interleaved (model.py:347-349,411-413) ----
         f32x16 tp[2 * HT];
@@ -544,7 +556,9 @@ hipError_t launch_fwd3_w(const Fwd3Args& a, hipStream_t stream) {
 template <class C>
 hipError_t launch_fwd3(const Fwd3Args& a, hipStream_t stream) {
     // 256-row workgroups need B > 32768 to put one on (almost) every CU; below that 128-row workgroups use twice the CUs
-    return a.B > 128 * 256 ? launch_fwd3_w<C, 8>(a, stream) : launch_fwd3_w<C, 4>(a, stream);
+    static const char* fw = getenv("LSNF_FORCE_WAVES");   // experiment knob (tools/): 4 or 8
+    const bool eight = fw ? atoi(fw) == 8 : a.B > 128 * 256;
+    return eight ? launch_fwd3_w<C, 8>(a, stream) : launch_fwd3_w<C, 4>(a, stream);
 }
 }  // namespace
 
@@ -555,9 +569,12 @@ hipError_t launch_fwd3(const Fwd3Args& a, hipStream_t stream) {
 hipError_t LSNF_FWD3_ENTRY(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                 const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                 float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
-                                int shape16, int fixup, hipStream_t stream) {
+                                int shape16, int fixup, hipStream_t stream, float* hdump) {
     Fwd3Args a;
     a.shape16 = shape16;
+    a.hdump = hdump ? hdump + (size_t)first_block * lsnf_dump_layout(B, g.nz, g.width).per_block : nullptr;
+    a.width = g.width;
+    if (hdump && !shape16) return hipErrorInvalidValue;      // (the dump is written by the L16 kernels)
     a.fixup = fixup;
     a.guard = reinterpret_cast<const unsigned*>(plan + g.off_guard);
 #if LSNF_L16_PARTS == 3

@@ -134,6 +134,26 @@ __device__ __forceinline__ void l16_store_tile(int t, const f32x16& x, float* __
             }
         }
 }
+// parameter-gradient dump (lsnf_layout.h LsnfDumpLayout): tile t of a (B, ld) row-major tensor in natural feature order;
+// v4: ld % 4 == 0 (rows 16-byte aligned)
+__device__ __forceinline__ void l16_store_plain(const f32x16& x, float* __restrict__ base, const long* rows, const bool* live,
+                                                int ld, int t, int g, bool v4) {
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            if (!live[st]) continue;
+            const int c0 = 32 * t + 16 * ft + 4 * g, b = (2 * ft + st) * 4;
+            float* zr = base + rows[st] * (long)ld;
+            if (v4) {
+                if (c0 < ld) { f32x4 v = {x[b], x[b + 1], x[b + 2], x[b + 3]}; *reinterpret_cast<f32x4*>(zr + c0) = v; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c0 + j < ld) zr[c0 + j] = x[b + j];
+            }
+        }
+}
 // bias block of one n-tile ([h][r] order of the 32x32 layout, lsnf_prep.hip bias_feature) -> L16 accumulators
 __device__ __forceinline__ f32x16 l16_bias_init(const float* cst, int g) {
     f32x16 a;

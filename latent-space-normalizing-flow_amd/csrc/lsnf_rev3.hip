@@ -4,6 +4,7 @@
 //   R2,R3,R4 : h = f(z1) -> [t; p]                                (forward panels S2..S4, 16x16x32 operand order)
 //   CI       : z2 = z2 / sigmoid(p) - t ; objective -= sum log sigmoid(p)     (model.py:436-438)
 //   I1       : z = ([z1,z2] @ W^-1) * exp(-3 logs) - b ; objective -= log|det W| + sum 3 logs  (:193-196, 270, 246)
+#include <stdlib.h>
 #include "lsnf_l16.h"
 
 namespace {
@@ -176,7 +177,9 @@ hipError_t launch_rev3_w(const Rev3Args& a, hipStream_t stream) {
 }
 template <class C>
 hipError_t launch_rev3(const Rev3Args& a, hipStream_t stream) {
-    return a.B > 128 * 256 ? launch_rev3_w<C, 8>(a, stream) : launch_rev3_w<C, 4>(a, stream);
+    static const char* fw = getenv("LSNF_FORCE_WAVES");   // experiment knob (tools/): 4 or 8
+    const bool eight = fw ? atoi(fw) == 8 : a.B > 128 * 256;
+    return eight ? launch_rev3_w<C, 8>(a, stream) : launch_rev3_w<C, 4>(a, stream);
 }
 }  // namespace
 

@@ -110,6 +110,18 @@ __device__ __forceinline__ void store_row_half(int t, int ft, const f32x4& x, fl
             if (f0 + j < half) zr[col0 + j] = x[j];
     }
 }
+// parameter-gradient dump (lsnf_layout.h LsnfDumpLayout): half-unit (nt, ft) of a (B, ld) row-major tensor in natural feature
+// order, row pointer zr = base + sample * ld; v4: ld % 4 == 0 (rows 16-byte aligned)
+__device__ __forceinline__ void store_plain_half(const f32x4& x, float* __restrict__ zr, int ld, int nt, int ft, int g, bool v4) {
+    const int c0 = 32 * nt + 16 * ft + 4 * g;
+    if (v4) {
+        if (c0 < ld) *reinterpret_cast<f32x4*>(zr + c0) = x;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c0 + j < ld) zr[c0 + j] = x[j];
+    }
+}
 // sum over the 4 lane groups of a per-sample value
 __device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
 

@@ -40,6 +40,8 @@ struct Small3BwdArgs {
     float step, ll_scale;
     LsnfRngArgs rng;
     int ll_mode, B, nz, half, depth, vec4;
+    float* dump; float* gl_total; int width;      // DUMP variant (parameter gradients, lsnf_params.hip): per block g_v, g_a1, g_a2,
+                                                  // g_t, g_p written for the batch contraction; G = sum_b dL/dlogdet_b
 };
 
 __device__ __forceinline__ f32x4 mask4(f32x4 a, unsigned nib) {
@@ -49,7 +51,7 @@ __device__ __forceinline__ f32x4 mask4(f32x4 a, unsigned nib) {
 }
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-template <class C>
+template <class C, bool DUMP>
 __global__ __launch_bounds__(256, 1) void lsnf_small3_bwd_kernel(const Small3BwdArgs a) {
     constexpr int HT = C::HT, WT = C::WT, NZT = C::NZT, NU2 = C::NU2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -125,10 +127,22 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_bwd_kernel(const Small3Bwd
         }
     }
 
+    const LsnfDumpLayout dl = lsnf_dump_layout(a.B, a.nz, a.width);
+    const bool w4 = (a.width & 3) == 0, h4 = (a.half & 3) == 0;
+    if constexpr (DUMP) {   // G = sum_b dL/dlogdet_b: one atomic per workgroup
+        if (wave == 0) {
+            float t = (live && g == 0) ? gl : 0.0f;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+            if (lane == 0) atomicAdd(a.gl_total, t);
+        }
+    }
+
     for (int blk = last; blk >= 0; --blk) {
         const float* gb = a.panels + (size_t)blk * C::BLOCKB;
         const int nb = blk > 0 ? blk - 1 : 0;                              // block 0 re-fetches its own panels: no loads under a branch
         const float* gbn = a.panels + (size_t)nb * C::BLOCKB;
+        float* dmp = (DUMP && live) ? a.dump + (size_t)blk * dl.per_block : nullptr;
 
         // ---- CB: coupling backward (model.py:414-418) on this wave's half-unit ----
         if (has1) {
@@ -141,6 +155,13 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_bwd_kernel(const Small3Bwd
             store_half(GTP + nt1 * S3_BTILE_FLOATS, ft1, gt, lane);
             store_half(GTP + (HT + nt1) * S3_BTILE_FLOATS, ft1, gp, lane);
             store_half(GV + (HT + nt1) * S3_BTILE_FLOATS, ft1, gt, lane);       // g_v2 = g_t
+            if constexpr (DUMP) {
+                if (dmp) {
+                    store_plain_half(gt, dmp + dl.off_gt + sample * (long)a.half, a.half, nt1, ft1, g, h4);
+                    store_plain_half(gp, dmp + dl.off_gp + sample * (long)a.half, a.half, nt1, ft1, g, h4);
+                    store_row_half<HT>(HT + nt1, ft1, gt, dmp + dl.off_gv + sample * (long)a.nz, a.half, g, vec4);
+                }
+            }
         }
         __syncthreads();
         // ---- B4: g_a2 = ([W3s W3p][g_t; g_p]) gated by h2 > 0 ----
@@ -148,7 +169,10 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_bwd_kernel(const Small3Bwd
 #pragma unroll
         for (int i = 0; i < NU2; ++i) {
             const f32x4 ga = mask4(unit_mma<2 * HT>(zero4(), wb4[i], GTP, lane), m2[i]);
-            if (hasw[i]) store_half(GA2 + (hw[i] >> 1) * S3_BTILE_FLOATS, hw[i] & 1, ga, lane);
+            if (hasw[i]) {
+                store_half(GA2 + (hw[i] >> 1) * S3_BTILE_FLOATS, hw[i] & 1, ga, lane);
+                if constexpr (DUMP) { if (dmp) store_plain_half(ga, dmp + dl.off_ga2 + sample * (long)a.width, a.width, hw[i] >> 1, hw[i] & 1, g, w4); }
+            }
         }
         __syncthreads();
         // ---- B3: g_a1 = (W2' g_a2) gated by h1 > 0 ----
@@ -157,7 +181,10 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_bwd_kernel(const Small3Bwd
 #pragma unroll
         for (int i = 0; i < NU2; ++i) {
             const f32x4 ga = mask4(unit_mma<WT>(zero4(), wb3[i], GA2, lane), m1[i]);
-            if (hasw[i]) store_half(GA1 + (hw[i] >> 1) * S3_BTILE_FLOATS, hw[i] & 1, ga, lane);
+            if (hasw[i]) {
+                store_half(GA1 + (hw[i] >> 1) * S3_BTILE_FLOATS, hw[i] & 1, ga, lane);
+                if constexpr (DUMP) { if (dmp) store_plain_half(ga, dmp + dl.off_ga1 + sample * (long)a.width, a.width, hw[i] >> 1, hw[i] & 1, g, w4); }
+            }
         }
         __syncthreads();
         // ---- B2: g_v1 = g_x1 (direct) + W1' g_a1 ----
@@ -166,7 +193,10 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_bwd_kernel(const Small3Bwd
         fetch_block_state(nb);                                             // next block's y2 / sigma / masks (this block's are consumed)
         {
             const f32x4 gv1 = unit_mma<WT>(gx1, wb2, GA1, lane);
-            if (has1) store_half(GV + nt1 * S3_BTILE_FLOATS, ft1, gv1, lane);
+            if (has1) {
+                store_half(GV + nt1 * S3_BTILE_FLOATS, ft1, gv1, lane);
+                if constexpr (DUMP) { if (dmp) store_row_half<HT>(nt1, ft1, gv1, dmp + dl.off_gv + sample * (long)a.nz, a.half, g, vec4); }
+            }
         }
         __syncthreads();
         // ---- B1: g_x = Wa [g_v1; g_v2] ----
@@ -243,9 +273,9 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_bwd_kernel(const Small3Bwd
 template <class C>
 hipError_t launch_small3_bwd(const Small3BwdArgs& a, hipStream_t stream) {
     const size_t lds = (size_t)C::L_END * sizeof(float);
-    auto kern = lsnf_small3_bwd_kernel<C>;
-    static unsigned long long lds_ok = 0;
-    if (hipError_t e = lsnf_allow_big_lds((const void*)kern, &lds_ok); e != hipSuccess) return e;
+    auto kern = a.dump ? lsnf_small3_bwd_kernel<C, true> : lsnf_small3_bwd_kernel<C, false>;
+    static unsigned long long lds_ok[2] = {0, 0};
+    if (hipError_t e = lsnf_allow_big_lds((const void*)kern, &lds_ok[a.dump ? 1 : 0]); e != hipSuccess) return e;
     const unsigned grid = (unsigned)((a.B + S3_SAMPLES - 1) / S3_SAMPLES);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
     return hipGetLastError();
@@ -255,9 +285,11 @@ hipError_t launch_small3_bwd(const Small3BwdArgs& a, hipStream_t stream) {
 // host-side dispatcher (called from lsnf_api.hip); needs the activation stash; hipErrorInvalidValue = not covered
 hipError_t lsnf_launch_small3_backward_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
                                          const float* act_saved, const float* g_z1, const float* g_logdet, int ll_mode,
-                                         float ll_scale, float* g_z_in, int vec4, hipStream_t stream, const LsnfLangevinArgs* lv) {
+                                         float ll_scale, float* g_z_in, int vec4, hipStream_t stream, const LsnfLangevinArgs* lv,
+                                         float* dump, float* gl_total) {
     if (!act_saved) return hipErrorInvalidValue;
     Small3BwdArgs a;
+    a.dump = dump; a.gl_total = gl_total; a.width = g.width;
     a.panels = plan + g.off_b3b_panels;
     a.z_out = z_out; a.z_saved = z_saved; a.act_saved = act_saved; a.g_z1 = g_z1; a.g_logdet = g_logdet; a.g_z_in = g_z_in;
     a.z_cur = nullptr; a.grad_g = nullptr; a.noise = nullptr; a.z_new = nullptr; a.gf_norm = nullptr; a.gg_norm = nullptr; a.step = 0.f;

@@ -41,7 +41,8 @@ struct Small3Args {
     const float* z_in; const float* objective;
     float* z_out; float* logdet_out; float* ll_out; float* z_saved; float* act_saved;
     double* stats;
-    int B, nz, half, n_blocks, vec4;
+    float* hdump;                      // NULL, or the parameter-gradient dump (LsnfDumpLayout) of block first_block: h1, h2 are written
+    int B, nz, half, n_blocks, vec4, width;
 };
 
 template <class C>
@@ -84,6 +85,8 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_fwd_kernel(const Small3Arg
                    load_row_half<HT>(hu >> 1, hu & 1, a.z_in + row * (long)a.nz, a.half, g, a.vec4), lane);
     float ell = (wave == 0 && a.objective) ? a.objective[row] : 0.0f;      // per-wave partial of the running log-det
     const LsnfActLayout al = lsnf_act_layout(a.B, HT, WT);
+    const LsnfDumpLayout dl = lsnf_dump_layout(a.B, a.nz, a.width);
+    const bool w4 = (a.width & 3) == 0;
     const size_t wtile = (size_t)(blockIdx.x >> 1);                       // 32-sample stash tile this workgroup is one half of
     const int st = (int)((blockIdx.x) & 1);                               // which half of that tile this workgroup is
     const int lane32 = 16 * st + n + 32 * (g & 1);                        // stash lane of (sample, feature-group parity)
@@ -98,6 +101,7 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_fwd_kernel(const Small3Arg
         float* Xc = XB + (blk & 1) * NZT * S3_BTILE_FLOATS;
         float* Xn = XB + ((blk + 1) & 1) * NZT * S3_BTILE_FLOATS;
         float* act = a.act_saved ? a.act_saved + (size_t)blk * al.per_block + wtile * al.per_tile : nullptr;
+        float* hd = (a.hdump && live) ? a.hdump + (size_t)blk * dl.per_block + sample * (long)a.width : nullptr;   // this sample's row of h1 / h2
 
         // ---- S1: v = Wa^T x + ca (model.py:244,268,187); this wave: v1[hu1], v2[hu1] ----
         UFrags<WT> w3[NU2];
@@ -117,6 +121,7 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_fwd_kernel(const Small3Arg
             const f32x4 h = relu4(unit_mma<HT>(unit_bias(cb + 32 * (C::P1 + nt), ft, g), w2[i], Xn, lane));
             if (hasw[i]) {
                 store_half(H1B + nt * S3_BTILE_FLOATS, ft, h, lane);
+                if (hd) store_plain_half(h, hd + dl.off_h1, a.width, nt, ft, g, w4);
                 if (act) {
                     unsigned c = 0;
 #pragma unroll
@@ -140,6 +145,7 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_fwd_kernel(const Small3Arg
             const f32x4 h = relu4(unit_mma<WT>(unit_bias(cb + 32 * (C::P1 + C::P2 + nt), ft, g), w3[i], H1B, lane));
             if (hasw[i]) {
                 store_half(H2B + nt * S3_BTILE_FLOATS, ft, h, lane);
+                if (hd) store_plain_half(h, hd + dl.off_h2, a.width, nt, ft, g, w4);
                 if (act) {
                     unsigned c = 0;
 #pragma unroll
@@ -231,8 +237,10 @@ hipError_t launch_small3_fwd(const Small3Args& a, hipStream_t stream) {
 hipError_t lsnf_launch_small3_forward(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                       const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                       float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
-                                      hipStream_t stream) {
+                                      hipStream_t stream, float* hdump) {
     Small3Args a;
+    a.hdump = hdump ? hdump + (size_t)first_block * lsnf_dump_layout(B, g.nz, g.width).per_block : nullptr;
+    a.width = g.width;
     a.consts = plan + g.off_fwd_const + (size_t)first_block * g.fwd_const_floats;
     a.panels3b = plan + g.off_f3b_panels + (size_t)first_block * g.f3_block_floats;
     a.act_saved = act_saved ? act_saved + (size_t)first_block * lsnf_act_layout(B, g.HT, g.WT).per_block : nullptr;

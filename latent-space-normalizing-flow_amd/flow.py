@@ -124,13 +124,15 @@ def forward(plan: FlowPlan, z: torch.Tensor, objective: Optional[torch.Tensor] =
             first_block: int = 0, n_blocks: Optional[int] = None, want_ll: bool = True,
             save_for_backward: bool = False, out: Optional[Tuple[torch.Tensor, ...]] = None,
             stats: Optional[torch.Tensor] = None, act_saved: Optional[torch.Tensor] = None,
-            z_saved_out: Optional[torch.Tensor] = None):
+            z_saved_out: Optional[torch.Tensor] = None, params_ws: Optional[torch.Tensor] = None):
     """One launch: blocks [first_block, first_block+n_blocks) on (B, nz) rows.
     Returns (z_out, logdet, ll or None, z_saved or None).  model.py:473-483 + train.py:317-319.
     act_saved: optional buffer from `new_act_saved()`, filled with the sigmoid / relu-mask stash that lets
     `backward_z` / the Langevin step skip recomputing the coupling MLP.
     stats: optional buffer from `new_stats()`; afterwards stats[4] = sum ll, stats[5] = sum logdet, stats[6] = B
-    (summed inside the kernel -- no separate reduction launch)."""
+    (summed inside the kernel -- no separate reduction launch).
+    params_ws: optional workspace from `new_params_workspace()` (with act_saved and the block outputs): the forward also
+    writes the hidden activations there, so that `backward_params(..., act_saved=, workspace=)` runs from the stash."""
     lib = _lib.load()
     _need_cuda(z, "z")
     if z.dim() != 2 or z.shape[1] != plan.nz:
@@ -153,7 +155,7 @@ def forward(plan: FlowPlan, z: torch.Tensor, objective: Optional[torch.Tensor] =
     with torch.cuda.device(z.device):
         rc = lib.lsnf_forward(_ptr(plan.buf), plan.nz, plan.width, plan.depth, plan.coupling, first_block, n_blocks, B,
                               _ptr(z), _ptr(objective), _ptr(z_out), _ptr(logdet), _ptr(ll), _ptr(saved),
-                              _ptr(act_saved), _ptr(stats), _stream_ptr(z.device))
+                              _ptr(act_saved), _ptr(params_ws), _ptr(stats), _stream_ptr(z.device))
     _lib.check(rc, "lsnf_forward")
     return z_out, logdet, ll, saved
 
@@ -185,6 +187,17 @@ def new_act_saved(plan: "FlowPlan", B: int, device) -> torch.Tensor:
     """Uninitialised activation stash for `forward(..., act_saved=)` on a batch of B rows."""
     n = _lib.load().lsnf_act_saved_floats(plan.nz, plan.width, plan.depth, int(B))
     return torch.empty(max(n, 1), dtype=torch.float32, device=device)
+
+
+def params_fast_path() -> bool:
+    """True if the math mode in force lets `backward_params` run from the forward's stash (every bf16x3-family mode)."""
+    return bool(_lib.load().lsnf_params_fast_path())
+
+
+def new_params_workspace(plan: "FlowPlan", B: int, device) -> torch.Tensor:
+    """Uninitialised workspace of `backward_params` for a batch of B rows (also the `params_ws` of `forward`)."""
+    n = _lib.load().lsnf_backward_params_workspace_floats(plan.nz, plan.width, plan.depth, int(B))
+    return torch.empty(max(n, 4), dtype=torch.float32, device=device)
 
 
 def new_stats(device) -> torch.Tensor:
@@ -303,22 +316,27 @@ def langevin_step(plan: FlowPlan, z: torch.Tensor, grad_g: Optional[torch.Tensor
 def backward_params(plan: FlowPlan, params: Sequence[torch.Tensor], z_in: torch.Tensor, z_out: torch.Tensor,
                     z_saved: Optional[torch.Tensor], g_z1: Optional[torch.Tensor] = None,
                     g_logdet: Optional[torch.Tensor] = None, ll_scale: Optional[float] = None,
-                    want_grad_z: bool = False, want_flat: bool = False, reuse_buffers: bool = False):
+                    want_grad_z: bool = False, want_flat: bool = False, reuse_buffers: bool = False,
+                    act_saved: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None):
     """dL/dtheta for the depth*12 live tensors (train.py:406-411).  Returns a list of gradients shaped like
     `params` (and dL/dz_in as a second value if want_grad_z; and, last, the ONE flat buffer the gradients are views
     of if want_flat -- a global norm / clip is then one reduction instead of 60).  reuse_buffers: keep the flat
     gradient buffer, its 60 views, the pointer tables and the workspace on the plan between calls (as long as the
     parameter storages and B do not change) -- the returned gradient tensors are then THE SAME objects every call,
-    overwritten in place (an optimizer that consumes .grad before the next call does not notice; ~0.2 ms of host time)."""
+    overwritten in place (an optimizer that consumes .grad before the next call does not notice; ~0.2 ms of host time).
+    act_saved + workspace: the stash and the `params_ws` the forward of THIS evaluation was given -- the backward then runs
+    from the stash on the bf16 matrix pipe instead of recomputing the coupling MLP in fp32 (`params_fast_path()`)."""
     lib = _lib.load()
     _need_cuda(z_in, "z_in")
     _need_cuda(z_out, "z_out")
     B = z_out.shape[0]
     if len(params) != plan.depth * LSNF_PARAMS_PER_BLOCK:
         raise LsnfError(f"expected {plan.depth * LSNF_PARAMS_PER_BLOCK} parameter tensors, got {len(params)}")
-    for name, t in (("z_saved", z_saved), ("g_z1", g_z1), ("g_logdet", g_logdet)):
+    for name, t in (("z_saved", z_saved), ("g_z1", g_z1), ("g_logdet", g_logdet), ("act_saved", act_saved), ("workspace", workspace)):
         if t is not None:
             _need_cuda(t, name)
+    if (act_saved is None) != (workspace is None):
+        raise LsnfError("act_saved and workspace go together: both from the forward of this evaluation")
     key = (tuple(p.data_ptr() for p in params), B, z_out.device, want_grad_z)
     st = plan.__dict__.get("_bp_state") if reuse_buffers else None
     if st is None or st["key"] != key:
@@ -329,7 +347,7 @@ def backward_params(plan: FlowPlan, params: Sequence[torch.Tensor], z_in: torch.
         sizes = [t.numel() for t in raw]
         flat = torch.empty(sum(sizes), dtype=torch.float32, device=z_out.device)
         grads = [g.view(t.shape) for g, t in zip(flat.split(sizes), raw)]
-        nws = lib.lsnf_backward_params_workspace_floats(plan.nz, plan.width, plan.depth, B)
+        nws = lib.lsnf_backward_params_workspace_floats(plan.nz, plan.width, plan.depth, B) if workspace is None else 0
         base, o, offs = flat.data_ptr(), 0, []
         for n in sizes:
             offs.append(base + o * 4)
@@ -341,9 +359,14 @@ def backward_params(plan: FlowPlan, params: Sequence[torch.Tensor], z_in: torch.
         if reuse_buffers:
             plan.__dict__["_bp_state"] = st
     flat, grads, g_in, ws, parr, garr = st["flat"], st["grads"], st["g_in"], st["ws"], st["parr"], st["garr"]
+    if workspace is not None:
+        need = lib.lsnf_backward_params_workspace_floats(plan.nz, plan.width, plan.depth, B)
+        if workspace.numel() < need:
+            raise LsnfError(f"workspace has {workspace.numel()} floats, lsnf_backward_params needs {need}")
+        ws = workspace
     with torch.cuda.device(z_out.device):
         rc = lib.lsnf_backward_params(_ptr(plan.buf), parr, garr, plan.nz, plan.width, plan.depth, plan.coupling, B,
-                                      _ptr(z_in), _ptr(z_out), _ptr(z_saved), _ptr(g_z1), _ptr(g_logdet),
+                                      _ptr(z_in), _ptr(z_out), _ptr(z_saved), _ptr(act_saved), _ptr(g_z1), _ptr(g_logdet),
                                       0 if ll_scale is None else 1, float(ll_scale or 0.0), _ptr(g_in), _ptr(ws),
                                       _stream_ptr(z_out.device))
     _lib.check(rc, "lsnf_backward_params")

@@ -106,10 +106,10 @@ class revnet2d(nn.Module):
 # ---------------------------------------------------------------------------------------------
 class _Upstream:
     """Hand-over between the two autograd nodes below (filled by _FlowStackFn.backward)."""
-    __slots__ = ("g_z1", "g_logdet", "z", "z1", "saved", "plan_key")
+    __slots__ = ("g_z1", "g_logdet", "z", "z1", "saved", "plan_key", "act", "ws")
 
     def __init__(self):
-        self.g_z1 = self.g_logdet = self.z = self.z1 = self.saved = self.plan_key = None
+        self.g_z1 = self.g_logdet = self.z = self.z1 = self.saved = self.plan_key = self.act = self.ws = None
 
 
 class _ParamGate(torch.autograd.Function):
@@ -129,7 +129,8 @@ class _ParamGate(torch.autograd.Function):
             raise LsnfError("parameter gradients requested before the flow's backward ran")
         if module._current_key() != h.plan_key:     # the LIVE parameters, not the key cached at the last _plan() call
             raise LsnfError("flow parameters were modified between forward and backward")
-        grads = flow.backward_params(module._plan(), module._param_list(), h.z, h.z1, h.saved, h.g_z1, h.g_logdet)
+        grads = flow.backward_params(module._plan(), module._param_list(), h.z, h.z1, h.saved, h.g_z1, h.g_logdet,
+                                     act_saved=h.act if h.ws is not None else None, workspace=h.ws)
         grads = [g if need else None for g, need in zip(grads, ctx.needs_input_grad[2:])]
         return (None, None, *grads)
 
@@ -142,12 +143,17 @@ class _FlowStackFn(torch.autograd.Function):
     def forward(ctx, module, holder, z, objective, token):
         plan = module._plan()
         # z needs a gradient (the Langevin sampler, train.py:316-323): also keep the sigmoid / relu-mask stash so
-        # that lsnf_backward_z does not recompute the coupling MLP
-        act = flow.new_act_saved(plan, z.shape[0], z.device) if (ctx.needs_input_grad[2] and z.shape[0]) else None
-        z1, logdet, _, saved = flow.forward(plan, z, objective, want_ll=False, save_for_backward=True, act_saved=act)
+        # that lsnf_backward_z does not recompute the coupling MLP.  z is a constant and the parameters are the leaves
+        # (the flow-MLE step, train.py:404-411): keep the stash AND let the forward write the hidden activations into
+        # the parameter-gradient workspace, so that lsnf_backward_params runs from the stash (flow.params_fast_path).
+        B = z.shape[0]
+        for_params = bool(B) and not ctx.needs_input_grad[2] and ctx.needs_input_grad[4] and flow.params_fast_path()
+        act = flow.new_act_saved(plan, B, z.device) if (B and (ctx.needs_input_grad[2] or for_params)) else None
+        ws = flow.new_params_workspace(plan, B, z.device) if for_params else None
+        z1, logdet, _, saved = flow.forward(plan, z, objective, want_ll=False, save_for_backward=True, act_saved=act, params_ws=ws)
         ctx.module, ctx.holder = module, holder
         ctx.plan_key = module._plan_key
-        ctx.act = act
+        ctx.act, ctx.ws = act, ws
         ctx.save_for_backward(z, z1, saved if saved is not None else z1.new_empty(0))
         return z1, logdet
 
@@ -167,6 +173,7 @@ class _FlowStackFn(torch.autograd.Function):
         g_tok = None
         if ctx.needs_input_grad[4]:
             h.g_z1, h.g_logdet, h.z, h.z1, h.saved, h.plan_key = g_z1, g_logdet, z, z1, saved_t, ctx.plan_key
+            h.act, h.ws = ctx.act, ctx.ws
             g_tok = z1.new_zeros(())
         return None, None, g_z, g_obj, g_tok
 
@@ -304,10 +311,17 @@ class _netF(nn.Module):
         if B == 0:
             raise LsnfError("mle_grads needs a non-empty batch")
         stats = flow.new_stats(z.device)
-        z1, _, _, saved = flow.forward(plan, z, None, want_ll=False, save_for_backward=True, stats=stats)
+        fast = flow.params_fast_path()         # forward keeps the stash + writes h1 / h2 for the contraction: nothing is recomputed
+        bufs = plan.__dict__.get("_mle_buffers") if reuse_buffers else None
+        if fast and (bufs is None or bufs[0] != (B, z.device)):
+            bufs = ((B, z.device), flow.new_act_saved(plan, B, z.device), flow.new_params_workspace(plan, B, z.device))
+            if reuse_buffers:
+                plan.__dict__["_mle_buffers"] = bufs
+        act, ws = (bufs[1], bufs[2]) if fast else (None, None)
+        z1, _, _, saved = flow.forward(plan, z, None, want_ll=False, save_for_backward=True, stats=stats, act_saved=act, params_ws=ws)
         params = self._param_list()
         grads, flat = flow.backward_params(plan, params, z, z1, saved, ll_scale=-1.0 / B, want_flat=True,
-                                           reuse_buffers=reuse_buffers and not accumulate)
+                                           reuse_buffers=reuse_buffers and not accumulate, act_saved=act, workspace=ws)
         if max_norm is not None:
             if accumulate:
                 raise LsnfError("max_norm clips the gradients of this call only: not with accumulate=True")

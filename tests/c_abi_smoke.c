@@ -74,7 +74,7 @@ int main(void) {
     int fails = 0;
     for (int family = 0; family < 2; ++family) {                 /* latency kernels, then throughput kernels */
         lsnf_set_small_batch_max(family == 0 ? (1 << 30) : 0);
-        LS(lsnf_forward(plan, NZ, W, DEPTH, 1, 0, DEPTH, B, dz, NULL, dz1, dld, dll, NULL, NULL, dstats, stream));
+        LS(lsnf_forward(plan, NZ, W, DEPTH, 1, 0, DEPTH, B, dz, NULL, dz1, dld, dll, NULL, NULL, NULL, dstats, stream));
         LS(lsnf_reverse(plan, NZ, W, DEPTH, 1, B, dz1, dld, dback, dobj, stream));
         CHECK(hipStreamSynchronize(stream));
         float* o = (float*)malloc(sizeof(float) * B * NZ); float ld[B], ll[B], ob[B]; double st[8];
@@ -101,6 +101,6 @@ int main(void) {
         free(o);
     }
     /* error path: geometry outside the supported range must be refused with a message, not crash */
-    if (lsnf_forward(plan, 130, W, DEPTH, 1, 0, DEPTH, B, dz, NULL, dz1, dld, dll, NULL, NULL, NULL, stream) != LSNF_E_GEOMETRY) { fprintf(stderr, "bad geometry accepted\n"); fails++; }
+    if (lsnf_forward(plan, 130, W, DEPTH, 1, 0, DEPTH, B, dz, NULL, dz1, dld, dll, NULL, NULL, NULL, NULL, stream) != LSNF_E_GEOMETRY) { fprintf(stderr, "bad geometry accepted\n"); fails++; }
     return fails ? 1 : 0;
 }

@@ -262,3 +262,44 @@ def test_parameter_gradients_run_to_run_spread_full_size(lsnf, gpu_device):
             worst = max(worst, (r[k] - ref).norm().item() / nrm)
     print("run-to-run spread of backward_params at B=65536: worst per-tensor rel-L2", worst)
     assert worst <= 2e-6
+
+
+@pytest.mark.parametrize("nz,width,B", [(128, 64, 100), (128, 64, 5000), (100, 64, 4500), (50, 33, 4100), (100, 128, 4200),
+                                         (128, 64, 14000), (128, 64, 40000), (128, 64, 65536)])
+def test_parameter_gradients_from_the_stash_match_the_recomputing_path(lsnf, gpu_device, nz, width, B):
+    """`lsnf_backward_params` fast path (forward keeps the activation stash and writes h1 / h2 into the workspace; the
+    backward runs from the stash on the bf16 matrix pipe: latency kernels at B <= 16 384, throughput kernels above) against
+    the recomputing fp32-MFMA path on the same inputs -- all 60 tensors and dL/dz; and against the float64 oracle on a
+    whole batch at the sizes where that is affordable (these also cover the LDS-staged batch contraction of lsnf_params.hip,
+    used from 4 096 rows, in its three row-vector widths: nz/width/half multiples of 4, of 2, odd)."""
+    depth = 5
+    p = O.init_params(nz, width, depth, seed=3)
+    params = lsnf.params_from_state_dict(p, depth, gpu_device)
+    plan = lsnf.prepare(params, nz, width, depth)
+    z = torch.randn(B, nz, generator=torch.Generator().manual_seed(B)).to(gpu_device)
+    assert lsnf.flow.params_fast_path()
+    act = lsnf.flow.new_act_saved(plan, B, gpu_device); act.fill_(float("nan"))
+    ws = lsnf.flow.new_params_workspace(plan, B, gpu_device); ws.fill_(float("nan"))
+    z1, _, _, saved = lsnf.forward(plan, z, want_ll=False, save_for_backward=True, act_saved=act, params_ws=ws)
+    fast, gz_fast = lsnf.backward_params(plan, params, z, z1, saved, ll_scale=-1.0 / B, want_grad_z=True, act_saved=act, workspace=ws)
+    fast = [g.clone() for g in fast]; gz_fast = gz_fast.clone()
+    z1b, _, _, savedb = lsnf.forward(plan, z, want_ll=False, save_for_backward=True)
+    assert torch.equal(z1, z1b)
+    slow, gz_slow = lsnf.backward_params(plan, params, z, z1b, savedb, ll_scale=-1.0 / B, want_grad_z=True)
+    for k, (a, b) in enumerate(zip(fast, slow)):
+        assert torch.isfinite(a).all()
+        assert (a - b).norm().item() <= 2e-5 * max(b.norm().item(), 1e-12), (k, lsnf.flow.BLOCK_PARAM_KEYS[k % 12])
+    ok = (O.relu_margin(p, z.cpu()) > KINK).to(gpu_device)
+    assert (gz_fast - gz_slow)[ok].norm().item() <= 1e-5 * gz_slow[ok].norm().item()
+    if B <= 6000:
+        ref = O.grad_neg_mean_ll_wrt_params(O.to_dtype(p, torch.float64), z.cpu().double())
+        keys = [O.block_prefix(i) + k for i in range(depth) for k in lsnf.flow.BLOCK_PARAM_KEYS]
+        for k, g in zip(keys, fast):
+            r = ref[k].reshape(g.shape)
+            # (thousands of rows: some pre-activation sits within fp32 rounding of a ReLU kink, where the two sides' gradients
+            #  differ -- measured worst case 1.2e-4 on one fc_1.w at B = 4 200, identical for both contraction kernels)
+            assert (g.cpu().double() - r).norm().item() <= (1e-4 if B <= 1000 else 5e-4) * max(r.norm().item(), 1e-9), k
+    # run-to-run spread of the fast path (fp32 atomics in the batch contraction), as bounded for the recomputing one
+    again = lsnf.backward_params(plan, params, z, z1, saved, ll_scale=-1.0 / B, act_saved=act, workspace=ws)
+    for a, b in zip(fast, again):
+        assert (a - b).norm().item() <= 2e-6 * max(a.norm().item(), 1e-12)
