@@ -181,6 +181,14 @@ int lsnf_backward_z(const float* plan, int nz, int width, int depth, int couplin
                     const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
                     float* g_z_in, void* stream);
 
+/* The activation stash of a forward that was run WITHOUT one (act_saved = NULL), rebuilt from its block outputs: the
+ * coupling MLP's input is the first half of the block's output (model.py:422), so sigmoid(p) and the two ReLU masks follow
+ * from z_out / z_saved alone (S2, S3 and the pre-sigmoid half of S4 per block; blocks in parallel).  lsnf_restash + the
+ * from-the-stash lsnf_backward_z replace the recomputing backward on the bf16 matrix pipe; the ABI allocates nothing, so
+ * the caller owns the stash (lsnf_act_saved_floats).  Needs a bf16x3-family math mode (LSNF_E_ARG otherwise). */
+int lsnf_restash(const float* plan, int nz, int width, int depth, int coupling, int B,
+                 const float* z_out, const float* z_saved, float* act_saved, void* stream);
+
 /* ---- fused Langevin update: replaces train.py:317-329 after the forward ---------------------
  * One launch computes g_f = d(-sum ll)/dz (as lsnf_backward_z with ll_mode=1, ll_scale=-1) and applies
  *     z_new = z_cur - 0.5*s^2 * (grad_g + g_f) + s * noise          (train.py:324,326)

@@ -34,6 +34,7 @@ _SIGNATURES = {
                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lsnf_params_fast_path": (c_int, []),
     "lsnf_act_saved_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "lsnf_restash": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lsnf_reverse": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int,
                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lsnf_backward_z": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int,

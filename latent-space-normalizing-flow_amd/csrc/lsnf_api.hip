@@ -37,6 +37,8 @@ hipError_t lsnf_launch_small3_forward(const LsnfGeo& g, const float* plan, int f
                                       const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                       float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
                                       hipStream_t stream, float* hdump = nullptr);
+hipError_t lsnf_launch_small3_restash(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
+                                      float* act_saved, int vec4, hipStream_t stream);
 hipError_t lsnf_launch_small_forward(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                      const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                      float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
@@ -284,6 +286,22 @@ size_t lsnf_act_saved_floats(int nz, int width, int depth, int B) {
     LsnfGeo g;
     if (lsnf_geo_init(&g, nz, width, depth, 1) || B < 0) return 0;   // independent of the coupling type
     return (size_t)depth * lsnf_act_layout(B, g.HT, g.WT).per_block;
+}
+
+int lsnf_restash(const float* plan, int nz, int width, int depth, int coupling, int B, const float* z_out,
+                 const float* z_saved, float* act_saved, void* stream) {
+    LsnfGeo g;
+    if (int rc = geo_or_fail(&g, nz, width, depth, coupling)) return rc;
+    if (B < 0 || B > (1 << 28)) return fail(LSNF_E_ARG, "lsnf_restash: B=%d out of range", B);
+    if (B == 0) return LSNF_OK;
+    if (!plan || !z_out || !act_saved || (depth > 1 && !z_saved)) return fail(LSNF_E_ARG, "lsnf_restash: NULL argument");
+    if (!aligned16(plan) || !aligned16(act_saved)) return fail(LSNF_E_ARG, "lsnf_restash: plan / act_saved must be 16-byte aligned");
+    if (!aligned4(z_out) || !aligned4(z_saved)) return fail(LSNF_E_ARG, "lsnf_restash: tensors must be 4-byte aligned");
+    if (!l16_math()) return fail(LSNF_E_ARG, "lsnf_restash: needs a bf16x3-family math mode (lsnf_params_fast_path() == 1)");
+    const hipError_t e = lsnf_launch_small3_restash(g, plan, B, z_out, z_saved, act_saved, row_vector_width(g, {z_out, z_saved}),
+                                                    (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "lsnf_restash launch");
+    return LSNF_OK;
 }
 
 int lsnf_reverse(const float* plan, int nz, int width, int depth, int coupling, int B, const float* z_in,

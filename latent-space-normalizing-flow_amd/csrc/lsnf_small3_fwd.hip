@@ -220,6 +220,100 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_fwd_kernel(const Small3Arg
     }
 }
 
+// ---- restash: the activation stash of a forward that was run WITHOUT one, rebuilt from the block outputs ------------
+// lsnf_backward_z without a stash used to recompute the coupling MLP inside the fp32-MFMA backward (54 us at B = 100).  The
+// MLP's input is the first half of the block's OUTPUT (v1 passes through the coupling, model.py:422), so the stash --
+// sigmoid(p) and the two ReLU masks -- follows from z_out / z_saved alone: S2, S3 and the pre-sigmoid half of S4 of every
+// block, blocks independent of each other (grid.y).  Backward = this kernel + the from-the-stash backward, both on the
+// bf16 matrix pipe.
+struct RestashArgs {
+    const float* consts; const float* panels3b;
+    const float* z_out; const float* z_saved; float* act_saved;
+    int B, nz, half, depth, vec4;
+};
+template <class C>
+__global__ __launch_bounds__(256, 1) void lsnf_small3_restash_kernel(const RestashArgs a) {
+    constexpr int HT = C::HT, WT = C::WT, NU2 = C::NU2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* V1B = smem;                                          // HT B-tiles: v1
+    float* H1B = V1B + HT * S3_BTILE_FLOATS;
+    float* H2B = H1B + WT * S3_BTILE_FLOATS;
+    unsigned* MASK = reinterpret_cast<unsigned*>(H2B + WT * S3_BTILE_FLOATS);      // [h1 | h2][WT][32]
+    float* cst = reinterpret_cast<float*>(MASK + 2 * WT * 32);
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int blk = blockIdx.y;
+    const bool has1 = wave < 2 * HT;
+    const int hu1 = has1 ? wave : 0, nt1 = hu1 >> 1, ft1 = hu1 & 1;
+    int hw[NU2]; bool hasw[NU2];
+#pragma unroll
+    for (int i = 0; i < NU2; ++i) { hasw[i] = wave + 4 * i < 2 * WT; hw[i] = hasw[i] ? wave + 4 * i : 0; }
+    const float* gblk = a.panels3b + (size_t)blk * C::BLOCK3;
+    UFrags<HT> w2[NU2];
+    UFrags<WT> w3[NU2];
+#pragma unroll
+    for (int i = 0; i < NU2; ++i) {
+        w2[i] = fetch_unit<HT>(gblk + C::OFF3_S2, hw[i] >> 1, hw[i] & 1, lane);
+        w3[i] = fetch_unit<WT>(gblk + C::OFF3_S3, hw[i] >> 1, hw[i] & 1, lane);
+    }
+    const UFrags<WT> w4p = fetch_unit<WT>(gblk + C::OFF3_S4, HT + nt1, ft1, lane);
+    const float* cb = a.consts + (size_t)blk * C::CONST_FLOATS;
+    for (int i = tid; i < C::CONST_FLOATS; i += 256) cst[i] = cb[i];
+    for (int i = tid; i < 2 * WT * 32; i += 256) MASK[i] = 0u;
+    const long sample = (long)blockIdx.x * S3_SAMPLES + n;
+    const long row = sample < a.B ? sample : (long)a.B - 1;
+    const float* ysrc = (blk == a.depth - 1) ? a.z_out + row * (long)a.nz : a.z_saved + ((size_t)blk * a.B + row) * a.nz;
+    for (int hu = wave; hu < 2 * HT; hu += 4)
+        store_half(V1B + (hu >> 1) * S3_BTILE_FLOATS, hu & 1, load_row_half<HT>(hu >> 1, hu & 1, ysrc, a.half, g, a.vec4), lane);
+    const LsnfActLayout al = lsnf_act_layout(a.B, HT, WT);
+    const size_t wtile = (size_t)(blockIdx.x >> 1);
+    const int st = (int)(blockIdx.x & 1);
+    const int lane32 = 16 * st + n + 32 * (g & 1);
+    float* act = a.act_saved + (size_t)blk * al.per_block + wtile * al.per_tile;
+    __syncthreads();
+    // ---- S2 (model.py:326-328,307) ----
+#pragma unroll
+    for (int i = 0; i < NU2; ++i) {
+        const int nt = hw[i] >> 1, ft = hw[i] & 1;
+        const f32x4 h = relu4(unit_mma<HT>(unit_bias(cst + 32 * (C::P1 + nt), ft, g), w2[i], V1B, lane));
+        if (hasw[i]) {
+            store_half(H1B + nt * S3_BTILE_FLOATS, ft, h, lane);
+            unsigned c = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c |= (h[r] > 0.0f ? 1u : 0u) << (4 * (2 * ft + (g >> 1)) + r);
+            atomicOr(&MASK[nt * 32 + n + 16 * (g & 1)], c);
+        }
+    }
+    __syncthreads();
+    // ---- S3 (model.py:326-328,308) ----
+#pragma unroll
+    for (int i = 0; i < NU2; ++i) {
+        const int nt = hw[i] >> 1, ft = hw[i] & 1;
+        const f32x4 h = relu4(unit_mma<WT>(unit_bias(cst + 32 * (C::P1 + C::P2 + nt), ft, g), w3[i], H1B, lane));
+        if (hasw[i]) {
+            store_half(H2B + nt * S3_BTILE_FLOATS, ft, h, lane);
+            unsigned c = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c |= (h[r] > 0.0f ? 1u : 0u) << (4 * (2 * ft + (g >> 1)) + r);
+            atomicOr(&MASK[(WT + nt) * 32 + n + 16 * (g & 1)], c);
+        }
+    }
+    __syncthreads();
+    // ---- masks out; pre-sigmoid half of S4 (model.py:347-349,413) -> sigma ----
+    if (tid < 2 * WT * 32) {
+        const int t = tid >> 5, j = tid & 31;
+        reinterpret_cast<unsigned*>(act + al.mask_off)[t * 64 + 16 * st + (j & 15) + 32 * (j >> 4)] = MASK[t * 32 + j];
+    }
+    const f32x4 pp = unit_mma<WT>(unit_bias(cst + 32 * (C::P1 + C::P2 + C::P3 + HT + nt1), ft1, g), w4p, H2B, lane);
+    if (has1) {
+        f32x4 sg;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { float sig, l2; lsnf_sigmoid_log2(pp[r], sig, l2); sg[r] = sig; }
+        reinterpret_cast<f32x4*>(act + (size_t)nt1 * 1024)[(2 * ft1 + (g >> 1)) * 64 + lane32] = sg;
+    }
+}
+
 template <class C>
 hipError_t launch_small3_fwd(const Small3Args& a, hipStream_t stream) {
     const size_t lds = ((size_t)C::L_CONST + (size_t)a.n_blocks * C::CONST_FLOATS) * sizeof(float);
@@ -249,5 +343,27 @@ hipError_t lsnf_launch_small3_forward(const LsnfGeo& g, const float* plan, int f
     if (g.HT == 1 && g.WT == 1) return launch_small3_fwd<Small3Cfg<1, 1>>(a, stream);
     if (g.HT == 2 && g.WT == 2) return launch_small3_fwd<Small3Cfg<2, 2>>(a, stream);
     if (g.HT == 2 && g.WT == 4) return launch_small3_fwd<Small3Cfg<2, 4>>(a, stream);
+    return hipErrorInvalidValue;
+}
+
+// the stash of a forward that kept none, from its block outputs (lsnf_api.hip lsnf_restash); hipErrorInvalidValue = not covered
+hipError_t lsnf_launch_small3_restash(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
+                                      float* act_saved, int vec4, hipStream_t stream) {
+    RestashArgs a;
+    a.consts = plan + g.off_fwd_const; a.panels3b = plan + g.off_f3b_panels;
+    a.z_out = z_out; a.z_saved = z_saved; a.act_saved = act_saved;
+    a.B = B; a.nz = g.nz; a.half = g.half; a.depth = g.depth; a.vec4 = vec4;
+    auto go = [&](auto cfg) -> hipError_t {
+        using C = decltype(cfg);
+        const size_t lds = ((size_t)(C::HT + 2 * C::WT) * S3_BTILE_FLOATS + 2 * C::WT * 32 + C::CONST_FLOATS) * sizeof(float);
+        auto kern = lsnf_small3_restash_kernel<C>;
+        static unsigned long long lds_ok = 0;
+        if (hipError_t e = lsnf_allow_big_lds((const void*)kern, &lds_ok); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((B + S3_SAMPLES - 1) / S3_SAMPLES), (unsigned)g.depth), dim3(256), lds, stream, a);
+        return hipGetLastError();
+    };
+    if (g.HT == 1 && g.WT == 1) return go(Small3Cfg<1, 1>{});
+    if (g.HT == 2 && g.WT == 2) return go(Small3Cfg<2, 2>{});
+    if (g.HT == 2 && g.WT == 4) return go(Small3Cfg<2, 4>{});
     return hipErrorInvalidValue;
 }

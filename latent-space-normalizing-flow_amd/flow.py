@@ -228,10 +228,17 @@ def backward_z(plan: FlowPlan, z_out: torch.Tensor, z_saved: Optional[torch.Tens
                ll_scale: Optional[float] = None, act_saved: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dL/dz_in of the full stack (train.py:323).  Either pass upstream gradients (g_z1, g_logdet) or
     ll_scale for L = ll_scale * sum_b ll_b (train.py:320: ll_scale = -1).  act_saved: the stash the forward
-    filled (same batch), or None to recompute the coupling MLP from z_saved."""
+    filled (same batch), or None: the stash is then rebuilt from the block outputs (`lsnf_restash`, bf16 matrix pipe;
+    in MATH_FP32 the fp32 backward recomputes the coupling MLP itself)."""
     lib = _lib.load()
     _need_cuda(z_out, "z_out")
     B = z_out.shape[0]
+    if act_saved is None and B > 0 and params_fast_path():
+        act_saved = new_act_saved(plan, B, z_out.device)
+        with torch.cuda.device(z_out.device):
+            rc = lib.lsnf_restash(_ptr(plan.buf), plan.nz, plan.width, plan.depth, plan.coupling, B, _ptr(z_out), _ptr(z_saved),
+                                  _ptr(act_saved), _stream_ptr(z_out.device))
+        _lib.check(rc, "lsnf_restash")
     for name, t in (("z_saved", z_saved), ("g_z1", g_z1), ("g_logdet", g_logdet), ("act_saved", act_saved)):
         if t is not None:
             _need_cuda(t, name)
