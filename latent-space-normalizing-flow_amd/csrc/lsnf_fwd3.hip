@@ -349,12 +349,12 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3b_kernel(const Fwd3
 
     F3_STAMP(0, "s_memtime");
     F3_STAMP(50, "s_memrealtime");
-    const long wbase = ((long)blockIdx.x * F3_WAVES + wave) * 32;     // first row of this wave
+    const int wbase = (blockIdx.x * F3_WAVES + wave) * 32;            // first row of this wave (B <= 2^28: 32-bit row indices)
 #if LSNF_L16_PARTS == 3
     if (a.fixup) {                                // fix-up pass of the fp16 forward: only workgroups in which a wave raised its flag
         unsigned* fl = reinterpret_cast<unsigned*>(smem);
         unsigned f = 0u;
-        if (wbase < a.B) f = __builtin_bit_cast(unsigned, a.logdet_out[wbase]) == LSNF_F16_SENTINEL_BITS ? 1u : 0u;
+        if (wbase < a.B) f = __builtin_bit_cast(unsigned, a.logdet_out[(long)wbase]) == LSNF_F16_SENTINEL_BITS ? 1u : 0u;
         if (lane == 0) fl[wave] = f;
         __syncthreads();
         unsigned any = 0u;
@@ -378,10 +378,9 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3b_kernel(const Fwd3
     pipe.template prime<first_kib(C::P1, C::KT1)>(a.panels3);
     for (int i = tid; i < a.n_blocks * C::CONST_FLOATS; i += THREADS) cst[i] = a.consts[i];
 
-    const long base = ((long)blockIdx.x * F3_WAVES + wave) * 32;
-    long sample[2], rows[2]; bool live[2];
+    int sample[2], rows[2]; bool live[2];
 #pragma unroll
-    for (int st = 0; st < 2; ++st) { sample[st] = base + 16 * st + n; live[st] = sample[st] < a.B; rows[st] = live[st] ? sample[st] : (long)a.B - 1; }
+    for (int st = 0; st < 2; ++st) { sample[st] = wbase + 16 * st + n; live[st] = sample[st] < a.B; rows[st] = live[st] ? sample[st] : a.B - 1; }
 
     f32x16 x[NZT];
 #pragma unroll
@@ -417,12 +416,26 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3b_kernel(const Fwd3
             l16_gemm_stage3<C::P1, C::KT1, first_kib(C::P2, C::KT2)>(
                 pipe, gblk, gblk + C::OFF3_S2, v, xs, [&](int t) { return l16_bias_init(cb + 32 * t, g); }, keep);
         }
-        if (!more) {             // last block: the v1 half is final (model.py:422) -- store it under the MFMAs of S2..S4
+        // f_width 128 with two waves per SIMD (256 registers): the four split tiles of h1 / h2 (96 registers), four finished and two
+        // running accumulators of S3 / S4 do not fit beside v (64): hipcc spills ~49 registers to scratch there.  Tried instead
+        // (PARK, off): v1 / v2 parked in this wave's OWN z_out rows between S2's split and the end of the block -- zero scratch,
+        // but 262 MB of extra row traffic per launch at B = 65 536: 186 us against 153 us with hipcc's spills (bf16x3; fp16x2
+        // 133 vs 92; tools/ab_c5.py, two alternations on one box).  The compiler's choice of WHAT to spill is the cheaper one.
+#ifdef LSNF_PARK_V
+        constexpr bool PARK = WT == 4 && F3_WAVES == 8;
+#else
+        constexpr bool PARK = false;
+#endif
+        if (PARK || !more) {     // last block: the v1 half is final (model.py:422) -- its stores drain under the MFMAs of S2..S4
 #pragma unroll
             for (int t = 0; t < HT; ++t) l16_store_tile<HT>(t, v[t], a.z_out, sample, live, a.nz, a.half, g, a.vec4);
         }
 #pragma unroll
         for (int st = 0; st < 2; ++st) { ell[st] = ell[st] + cb[32 * C::NP + 0]; ell[st] = ell[st] + cb[32 * C::NP + 1]; }
+        if constexpr (PARK) {
+#pragma unroll
+            for (int t = HT; t < NZT; ++t) l16_store_tile<HT>(t, v[t], a.z_out, sample, live, a.nz, a.half, g, a.vec4);
+        }
         // ---- S2: h1 = relu(actnorm(v1 @ W1))  (model.py:326-328,307) ----
         f32x16 h1[WT];
         {
@@ -465,6 +478,10 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3b_kernel(const Fwd3
             l16_gemm_stage3<C::P4, C::KT4, first_kib(C::P1, C::KT1)>(
                 pipe, gblk + C::OFF3_S4, gnext, tp, hs,
                 [&](int t) { return l16_bias_init(cb + 32 * (C::P1 + C::P2 + C::P3 + t), g); }, keep);
+        }
+        if constexpr (PARK) {        // v back from its parking place (rows of dead samples: the clamped row's values, never stored)
+#pragma unroll
+            for (int t = 0; t < NZT; ++t) v[t] = l16_load_tile<HT>(t, a.z_out, rows, a.nz, a.half, g, a.vec4);
         }
         // ---- coupling + per-sample log-scale reduction (model.py:414-418), concat (:422) ----
         float lsum[2] = {0.0f, 0.0f};
@@ -509,12 +526,15 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3b_kernel(const Fwd3
     for (int st = 0; st < 2; ++st) {
         ll[st] = (-0.5f * l16_group_sum(ss[st]) + 1.8378770664093453f) + ell[st];
         if (live[st] && g == 0) {
+            int smp = sample[st];
+            asm volatile("" : "+v"(smp));       // (keeps hipcc from forming the two store addresses in the prologue and carrying
+                                                //  them -- 4 registers -- through the whole stack: they were the last scratch spill)
             float ld = ell[st];
 #if LSNF_L16_PARTS == 2
             if (wave_bad && st == 0 && n == 0) ld = __builtin_bit_cast(float, LSNF_F16_SENTINEL_BITS);
 #endif
-            a.logdet_out[sample[st]] = ld;
-            if (a.ll_out) a.ll_out[sample[st]] = ll[st];
+            a.logdet_out[smp] = ld;
+            if (a.ll_out) a.ll_out[smp] = ll[st];
         }
     }
     if (a.stats) {   // kernel-uniform: batch sums of ll and logdet, one pair of fp64 atomics per workgroup
@@ -557,7 +577,8 @@ template <class C>
 hipError_t launch_fwd3(const Fwd3Args& a, hipStream_t stream) {
     // 256-row workgroups need B > 32768 to put one on (almost) every CU; below that 128-row workgroups use twice the CUs
     static const char* fw = getenv("LSNF_FORCE_WAVES");   // experiment knob (tools/): 4 or 8
-    const bool eight = fw ? atoi(fw) == 8 : a.B > 128 * 256;
+    bool eight = fw ? atoi(fw) == 8 : a.B > 128 * 256;
+    if (!a.shape16 && C::WT == 4) eight = false;          // (the 32x32x16 comparison kernel does not fit 256 registers at f_width 128)
     return eight ? launch_fwd3_w<C, 8>(a, stream) : launch_fwd3_w<C, 4>(a, stream);
 }
 }  // namespace

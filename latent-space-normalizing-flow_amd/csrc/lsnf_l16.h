@@ -85,8 +85,9 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // feature offset (within a 32-feature tile) of the first of the 4 registers (ft, *) of lane group g
 __device__ __forceinline__ constexpr int l16_feat0(int ft, int g) { return 16 * ft + 4 * g; }
 
-template <int HT>
-__device__ __forceinline__ f32x16 l16_load_tile(int t, const float* __restrict__ z, const long* rows, int nz, int half, int g, int vw) {
+// (R: long or int row indices -- 32-bit ones halve the registers that stay live from the prologue to the final stores)
+template <int HT, class R>
+__device__ __forceinline__ f32x16 l16_load_tile(int t, const float* __restrict__ z, const R* rows, int nz, int half, int g, int vw) {
     f32x16 x;
     const int hh = t / HT, tt = t % HT;
 #pragma unroll
@@ -94,7 +95,7 @@ __device__ __forceinline__ f32x16 l16_load_tile(int t, const float* __restrict__
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             const int f0 = 32 * tt + l16_feat0(ft, g), col0 = hh * half + f0, b = (2 * ft + st) * 4;
-            const float* zr = z + rows[st] * (long)nz;
+            const float* zr = z + (long)rows[st] * (long)nz;
             if (vw == 4) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (f0 < half) v = *reinterpret_cast<const f32x4*>(zr + col0);
@@ -111,8 +112,8 @@ __device__ __forceinline__ f32x16 l16_load_tile(int t, const float* __restrict__
         }
     return x;
 }
-template <int HT>
-__device__ __forceinline__ void l16_store_tile(int t, const f32x16& x, float* __restrict__ z, const long* rows, const bool* live,
+template <int HT, class R>
+__device__ __forceinline__ void l16_store_tile(int t, const f32x16& x, float* __restrict__ z, const R* rows, const bool* live,
                                                int nz, int half, int g, int vw) {
     const int hh = t / HT, tt = t % HT;
 #pragma unroll
@@ -121,7 +122,7 @@ __device__ __forceinline__ void l16_store_tile(int t, const f32x16& x, float* __
         for (int st = 0; st < 2; ++st) {
             if (!live[st]) continue;
             const int f0 = 32 * tt + l16_feat0(ft, g), col0 = hh * half + f0, b = (2 * ft + st) * 4;
-            float* zr = z + rows[st] * (long)nz;
+            float* zr = z + (long)rows[st] * (long)nz;
             if (vw == 4) {
                 if (f0 < half) { f32x4 v = {x[b], x[b + 1], x[b + 2], x[b + 3]}; *reinterpret_cast<f32x4*>(zr + col0) = v; }
             } else if (vw == 2) {
@@ -136,7 +137,8 @@ __device__ __forceinline__ void l16_store_tile(int t, const f32x16& x, float* __
 }
 // parameter-gradient dump (lsnf_layout.h LsnfDumpLayout): tile t of a (B, ld) row-major tensor in natural feature order;
 // v4: ld % 4 == 0 (rows 16-byte aligned)
-__device__ __forceinline__ void l16_store_plain(const f32x16& x, float* __restrict__ base, const long* rows, const bool* live,
+template <class R>
+__device__ __forceinline__ void l16_store_plain(const f32x16& x, float* __restrict__ base, const R* rows, const bool* live,
                                                 int ld, int t, int g, bool v4) {
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft)
@@ -144,7 +146,7 @@ __device__ __forceinline__ void l16_store_plain(const f32x16& x, float* __restri
         for (int st = 0; st < 2; ++st) {
             if (!live[st]) continue;
             const int c0 = 32 * t + 16 * ft + 4 * g, b = (2 * ft + st) * 4;
-            float* zr = base + rows[st] * (long)ld;
+            float* zr = base + (long)rows[st] * (long)ld;
             if (v4) {
                 if (c0 < ld) { f32x4 v = {x[b], x[b + 1], x[b + 2], x[b + 3]}; *reinterpret_cast<f32x4*>(zr + c0) = v; }
             } else {

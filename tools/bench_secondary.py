@@ -45,7 +45,7 @@ for (tag, nz, w, B) in [("C2/C4 SVHN/CelebA nz=100 w=64 B=100", 100, 64, 100), (
     r = {"config": tag, "B": B}
     r["forward_logprob_us"] = timeit(lambda: lsnf_amd.forward(plan, z), n)
     if B > 16384:
-        names = {0: "fp32", 1: "bf16x3", 2: "bf16x3_32", 3: "fp16x2"}
+        names = {0: "fp32", 1: "bf16x3", 2: "bf16x3_32", 3: "fp16x2", 4: "bf16x3_pipe"}
         pm = lsnf_amd.flow.set_math_mode(-1)
         r["default_math_mode"] = names[pm]
         for om in (0, 1, 3):

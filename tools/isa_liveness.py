@@ -64,7 +64,7 @@ def main():
     top = int(sys.argv[sys.argv.index('--top') + 1]) if '--top' in sys.argv else 15
     txt = open(path).read().split('\n')
     start = next(i for i, l in enumerate(txt) if key in l and l.split(';')[0].strip().endswith(':') and not l.startswith('.'))
-    end = next(i for i in range(start, len(txt)) if 's_endpgm' in txt[i])
+    end = next(i for i in range(start, len(txt)) if txt[i].startswith('.Lfunc_end'))     # (a kernel may hold several s_endpgm)
     ins = parse(txt[start + 1:end + 1])
     n = len(ins)
     labels = {t: i for i, (op, t, _, _, _) in enumerate(ins) if op == 'label'}
@@ -73,6 +73,8 @@ def main():
         s = []
         if op.startswith('s_branch'):
             s = [labels[t]] if t in labels else []
+        elif op.startswith('s_endpgm'):
+            s = []
         else:
             if i + 1 < n:
                 s.append(i + 1)
