@@ -263,7 +263,14 @@ class PhiloxNoise:
         self.seed, self.offset, self.row0, self.offset_dev = int(seed), int(offset), int(row0), offset_dev
 
     def step(self, n: int = 1) -> "PhiloxNoise":
+        """A NEW generator n steps further on (this one is unchanged)."""
         return PhiloxNoise(self.seed, self.offset + n, self.row0, self.offset_dev)
+
+    def advance(self, n: int = 1) -> "PhiloxNoise":
+        """Moves THIS generator n steps on, in place (the K-step sampler calls it with K when it returns, so that a
+        generator kept across training iterations never repeats a draw)."""
+        self.offset += int(n)
+        return self
 
     def _c(self):
         mask = (1 << 64) - 1
@@ -296,7 +303,7 @@ def langevin_step(plan: FlowPlan, z: torch.Tensor, grad_g: Optional[torch.Tensor
             if t.shape != z.shape:
                 raise LsnfError(f"{name} must have the shape of z")
     cache = plan.__dict__.setdefault("_langevin_buffers", {}) if reuse_buffers else None
-    key = (B, z.device)
+    key = (B, z.device, torch.cuda.current_stream(z.device).cuda_stream)     # (two streams sharing one plan must not share buffers)
     bufs = cache.get(key) if cache is not None else None
     if bufs is None:
         f32 = dict(dtype=torch.float32, device=z.device)
@@ -304,7 +311,8 @@ def langevin_step(plan: FlowPlan, z: torch.Tensor, grad_g: Optional[torch.Tensor
                 "saved": torch.empty((plan.depth - 1, B, plan.nz), **f32) if plan.depth > 1 else None,
                 "gf": torch.empty(B, **f32), "gg": torch.empty(B, **f32)}
         if cache is not None:
-            cache.clear()                    # one batch size at a time
+            for k in [k for k in cache if k[2] == key[2]]:
+                del cache[k]                 # one batch size at a time per stream
             cache[key] = bufs
     act, saved = bufs["act"], bufs["saved"]
     z1, logdet, ll, _ = forward(plan, z, None, want_ll=True, out=bufs["out"], act_saved=act, z_saved_out=saved)
@@ -344,8 +352,8 @@ def backward_params(plan: FlowPlan, params: Sequence[torch.Tensor], z_in: torch.
             _need_cuda(t, name)
     if (act_saved is None) != (workspace is None):
         raise LsnfError("act_saved and workspace go together: both from the forward of this evaluation")
-    key = (tuple(p.data_ptr() for p in params), B, z_out.device, want_grad_z)
-    st = plan.__dict__.get("_bp_state") if reuse_buffers else None
+    key = (tuple(p.data_ptr() for p in params), B, z_out.device, want_grad_z, torch.cuda.current_stream(z_out.device).cuda_stream)
+    st = plan.__dict__.get("_bp_state") if reuse_buffers else None     # (keyed by stream too: a second stream re-allocates)
     if st is None or st["key"] != key:
         # one flat gradient buffer, handed out as views (60 separate allocations cost ~200 us of host time)
         raw = [p.detach() for p in params]

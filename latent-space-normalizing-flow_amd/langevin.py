@@ -21,7 +21,9 @@ def sample_langevin_post_z_with_flow(z, x, netG: nn.Module, netF, *, g_l_steps: 
     """Returns (z_k detached (B,nz,1,1), mean |z_grad_g|, mean |z_grad_f|, f_log_lkhd of the last step's input).
     Noise (train.py:325-326): `torch.randn` draws (optionally from `generator`), or, with `philox` =
     `flow.PhiloxNoise(seed, offset, row0)`, drawn inside the update kernel (step k uses offset + k): no randn
-    launch, no (B, nz) noise tensor, and the same draws however the rows are sharded over GPUs."""
+    launch, no (B, nz) noise tensor, and the same draws however the rows are sharded over GPUs.  On return `philox` has
+    been ADVANCED by g_l_steps (in place): a generator object kept across training iterations continues its stream
+    instead of repeating it."""
     z = z.clone().detach()
     B, nz = z.shape[0], z.shape[1]
     mse = nn.MSELoss(reduction="sum")
@@ -41,6 +43,8 @@ def sample_langevin_post_z_with_flow(z, x, netG: nn.Module, netF, *, g_l_steps: 
         f_log_lkhd = -ll.sum()                                                               # train.py:320
         gg_norm, gf_norm = gg.mean(), gf.mean()                                              # train.py:328-329
         z = z_new.view(B, nz, 1, 1)
+    if philox is not None and g_l_with_noise:
+        philox.advance(g_l_steps)
     return z.detach(), gg_norm, gf_norm, f_log_lkhd
 
 

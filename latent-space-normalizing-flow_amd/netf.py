@@ -313,8 +313,9 @@ class _netF(nn.Module):
         stats = flow.new_stats(z.device)
         fast = flow.params_fast_path()         # forward keeps the stash + writes h1 / h2 for the contraction: nothing is recomputed
         bufs = plan.__dict__.get("_mle_buffers") if reuse_buffers else None
-        if fast and (bufs is None or bufs[0] != (B, z.device)):
-            bufs = ((B, z.device), flow.new_act_saved(plan, B, z.device), flow.new_params_workspace(plan, B, z.device))
+        bkey = (B, z.device, torch.cuda.current_stream(z.device).cuda_stream)
+        if fast and (bufs is None or bufs[0] != bkey):
+            bufs = (bkey, flow.new_act_saved(plan, B, z.device), flow.new_params_workspace(plan, B, z.device))
             if reuse_buffers:
                 plan.__dict__["_mle_buffers"] = bufs
         act, ws = (bufs[1], bufs[2]) if fast else (None, None)

@@ -208,3 +208,26 @@ def test_parameter_update_between_forward_and_backward_raises(monkeypatch):
     net.invalidate_plan()
     net(z, torch.zeros(3))
     assert calls["prepare"] == n + 1
+
+
+def test_philox_generator_advances_across_sampler_calls():
+    """a `PhiloxNoise` kept across training iterations must not repeat its draws: `step()` is functional,
+    `advance()` moves the object, and the K-step sampler advances the caller's generator by K when it returns."""
+    from lsnf_amd import flow, langevin
+    g = flow.PhiloxNoise(seed=5, offset=10, row0=3)
+    h = g.step(4)
+    assert (g.offset, h.offset, h.seed, h.row0) == (10, 14, 5, 3)
+    assert g.advance(2) is g and g.offset == 12
+
+    class FakeF:                                       # stands in for _netF.langevin_step (no GPU here): records the offsets it is given
+        def __init__(self): self.offsets = []
+        def langevin_step(self, z2d, gg, noise, s, reuse_buffers=False):
+            self.offsets.append(noise.offset)
+            return z2d - 0.0 * gg, torch.zeros(z2d.shape[0]), torch.zeros(z2d.shape[0]), torch.zeros(z2d.shape[0])
+    netG = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(6, 12))
+    f = FakeF()
+    ph = flow.PhiloxNoise(seed=1, offset=100)
+    z0, x = torch.randn(4, 6, 1, 1), torch.randn(4, 12)
+    for _ in range(2):
+        langevin.sample_langevin_post_z_with_flow(z0, x, netG, f, g_l_steps=3, g_l_step_size=0.1, g_llhd_sigma=0.3, philox=ph)
+    assert f.offsets == [100, 101, 102, 103, 104, 105] and ph.offset == 106
