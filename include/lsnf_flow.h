@@ -88,7 +88,10 @@ int lsnf_set_small_batch_max(int rows);
  *                      or slower than LSNF_MATH_BF16X3; kept as the reference point for that finding.
  *   LSNF_MATH_FP16X2 : (opt-in; NARROWER than the reference's fp32: 11 + 11 operand bits) throughput forward and reverse
  *                      with both operands split into two fp16 terms, three fp16 MFMAs per product (csrc/lsnf_fwd2h.hip;
- *                      dropped terms <= 2^-22 |w||x|); half the matrix work of LSNF_MATH_BF16X3.  fp16's range is
+ *                      dropped terms <= 2^-22 |w||x|; operands below 2^-3 in magnitude additionally carry an ABSOLUTE
+ *                      error of up to 2^-25, because their second term falls into fp16's subnormals -- relative accuracy
+ *                      of small-magnitude latents and their gradients is not fp32's); half the matrix work of
+ *                      LSNF_MATH_BF16X3.  fp16's range is
  *                      guarded: a wave that meets an operand (or folded weight) at or beyond 65504 flags its first output
  *                      element, and the LSNF_MATH_BF16X3 kernel queued behind the launch recomputes the flagged
  *                      workgroups (an early-exit launch otherwise), so results are finite wherever the fp32

@@ -35,6 +35,25 @@ __device__ __forceinline__ void mfma_block(acc_t& c0, acc_t& c1, const bf16x8& a
     __builtin_amdgcn_sched_barrier(0);
 }
 // PAIRS element pairs x 9 VALU (cvt_pk, 2 shift/and, 2 sub, cvt_pk, 2 shift/and+sub...) ~ the bf16x3 operand split
+// the MFMA block with the wave idling NOP+1 cycles after every MFMA: does a back-to-back MFMA stream hold the SIMD's VALU issue
+// port (head-of-line) so that the partner wave's VALU cannot slip in, and do the gaps let it in?
+template <int NM, int NOP>
+__device__ __forceinline__ void mfma_block_gaps(acc_t& c0, acc_t& c1, const bf16x8& a, const bf16x8& b, const bf16x8& b2) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < NM / 2; ++u) {
+#ifdef SHAPE32
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop %0" :: "n"(NOP)); asm volatile("s_nop %0" :: "n"(NOP)); __builtin_amdgcn_sched_barrier(0);
+#else
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop %0" :: "n"(NOP)); __builtin_amdgcn_sched_barrier(0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b2, c1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop %0" :: "n"(NOP)); __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
 template <int PAIRS>
 __device__ __forceinline__ void valu_block(float* v, unsigned& sink) {
     __builtin_amdgcn_sched_barrier(0);
@@ -70,6 +89,19 @@ __global__ __launch_bounds__(512, 1) void k(float* out, int iters, float a0, uns
             if (MODE != 6) __builtin_amdgcn_s_barrier();
             if (wave < 4) { mfma_block<NM>(c0, c1, a, b, b2); valu_block<PAIRS>(v, sink); }
             else          { valu_block<PAIRS>(v, sink); mfma_block<NM>(c0, c1, a, b, b2); }
+        } else if (MODE >= 10 && MODE < 30) {          // staggered, gaps of MODE-10 after every MFMA
+            __builtin_amdgcn_s_barrier();
+            if (wave < 4) { mfma_block_gaps<NM, MODE - 10>(c0, c1, a, b, b2); valu_block<PAIRS>(v, sink); }
+            else          { valu_block<PAIRS>(v, sink); mfma_block_gaps<NM, MODE - 10>(c0, c1, a, b, b2); }
+        } else if (MODE >= 30 && MODE < 50) {          // the same + s_setprio 1 around the MFMA phase
+            __builtin_amdgcn_s_barrier();
+            if (wave < 4) { __builtin_amdgcn_s_setprio(1); mfma_block_gaps<NM, MODE - 30>(c0, c1, a, b, b2); __builtin_amdgcn_s_setprio(0); valu_block<PAIRS>(v, sink); }
+            else          { valu_block<PAIRS>(v, sink); __builtin_amdgcn_s_setprio(1); mfma_block_gaps<NM, MODE - 30>(c0, c1, a, b, b2); __builtin_amdgcn_s_setprio(0); }
+        } else if (MODE >= 50 && MODE < 70) {          // MFMA only, with the gaps (what the gaps cost by themselves)
+            mfma_block_gaps<NM, MODE - 50>(c0, c1, a, b, b2);
+        } else if (MODE >= 70 && MODE < 90) {          // in phase [bar, MFMA with gaps + prio, VALU]: the older wave runs ahead by itself
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1); mfma_block_gaps<NM, MODE - 70>(c0, c1, a, b, b2); __builtin_amdgcn_s_setprio(0); valu_block<PAIRS>(v, sink);
         } else if (MODE == 5) {
             __builtin_amdgcn_s_barrier();
             // the same work, interleaved by the scheduler: groups of 1 MFMA + (9*PAIRS/NM) VALU
@@ -132,7 +164,18 @@ template <int NM, int PAIRS> void suite(int iters) {
     run<5, NM, PAIRS>("interleaved inside every wave", iters);
     run<6, NM, PAIRS>("staggered, no barrier", iters);
 }
-int main() {
+template <int NM, int PAIRS, int NOP> void gaps(int iters) {
+    char nm[96];
+    snprintf(nm, sizeof nm, "MFMA only, s_nop %d after each", NOP);            run<50 + NOP, NM, PAIRS>(nm, iters);
+    snprintf(nm, sizeof nm, "staggered, s_nop %d gaps", NOP);                  run<10 + NOP, NM, PAIRS>(nm, iters);
+    snprintf(nm, sizeof nm, "staggered, s_nop %d gaps, setprio in MFMA", NOP); run<30 + NOP, NM, PAIRS>(nm, iters);
+    snprintf(nm, sizeof nm, "in phase, s_nop %d gaps, setprio in MFMA", NOP);  run<70 + NOP, NM, PAIRS>(nm, iters);
+}
+int main(int argc, char** argv) {
+    if (argc > 1) {      // the gap experiment
+        gaps<96, 16, 0>(200); gaps<96, 16, 1>(200); gaps<96, 16, 3>(200); gaps<96, 16, 5>(200); gaps<96, 16, 7>(200); gaps<96, 16, 9>(200); gaps<96, 16, 11>(200);
+        return 0;
+    }
     suite<96, 16>(200);     // VALU/MFMA issue-cycle ratio 144*4 / 96*16 = 0.375
     suite<96, 32>(200);     // 0.75
     suite<192, 32>(100);    // 0.375, longer phases
