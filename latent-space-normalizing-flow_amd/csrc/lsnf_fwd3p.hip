@@ -26,6 +26,7 @@
 // Same math, same prepared weights (plan region off_f3_panels) and the same I/O contract as lsnf_fwd3_kernel; replaces
 // reference model.py:473-483 + train.py:317-319.  Covers HT = 2 (nz in 66..128) without the backward's stash / block
 // outputs (lsnf_forward dispatches those calls to lsnf_fwd3.hip).
+#include <stdlib.h>
 #include "lsnf_l16.h"
 
 #if LSNF_L16_PARTS != 3
@@ -393,6 +394,370 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3p_kernel(const Fwd3pA
     P_STAMP(51, "s_memrealtime");
 }
 
+// =====================================================================================================================
+// The same pipeline on v_mfma_f32_16x16x32_bf16 (the "L16" lane layout of lsnf_l16.h, the weights of plan region
+// off_f3b_panels).  Why a second form: the 32x32x16 kernel above needs fewer cycles than lsnf_fwd3b_kernel but the chip
+// sustains a ~12 % lower clock under that MFMA shape.  tools/micro/shadow.hip: an MFMA of either shape holds the SIMD's
+// VALU issue for ~12 cycles; the 16-cycle 16x16x32 then leaves ONE 4-cycle slot, and one independent VALU per MFMA in that
+// slot is free (7.41 vs 7.20 ns per MFMA with two waves per SIMD), two cost +15 %.  So here a step = 12 MFMAs (one
+// 16-feature half of an output tile x one 32-feature k-tile x two sample tiles x six terms) carries 12..24 VALU.
+// =====================================================================================================================
+struct Tile16 { f32x4v q[4]; };                  // q[2*ft + st]: features 16*ft + 4*g + r of sample 16*st + n
+struct SplitTile16 { unsigned d[2][3][4]; };     // [st][part][dword 2*ft + j] = the B operands of one k-tile
+
+__device__ __forceinline__ Tile16 to_tile16(const f32x16& x) {
+    Tile16 t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t.q[q][r] = x[4 * q + r];
+    return t;
+}
+__device__ __forceinline__ f32x16 from_tile16(const Tile16& t) {
+    f32x16 x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[4 * q + r] = t.q[q][r];
+    return x;
+}
+__device__ __forceinline__ Tile16 tile16_bias(const float* cst, int g) {
+    Tile16 t;
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(cst + (g & 1) * 16 + 4 * (2 * ft + (g >> 1)));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { t.q[2 * ft][r] = v[r]; t.q[2 * ft + 1][r] = v[r]; }
+    }
+    return t;
+}
+// quad q = 2*ft + st of a tile (optionally through ReLU) -> dwords 2*ft, 2*ft + 1 of sample tile st: 18 (22) VALU
+template <bool RELU>
+__device__ __forceinline__ void split_q16(const Tile16& x, int q, SplitTile16& out) {
+    const int ft = q >> 1, st = q & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float a = x.q[q][2 * j], b = x.q[q][2 * j + 1];
+        if (RELU) { a = fmaxf(a, 0.0f); b = fmaxf(b, 0.0f); }
+        const unsigned p1 = pk_bf16(a, b);
+        a -= __builtin_bit_cast(float, p1 << 16); b -= __builtin_bit_cast(float, p1 & 0xffff0000u);
+        const unsigned p2 = pk_bf16(a, b);
+        a -= __builtin_bit_cast(float, p2 << 16); b -= __builtin_bit_cast(float, p2 & 0xffff0000u);
+        const int d = 2 * ft + j;
+        out.d[st][0][d] = p1; out.d[st][1][d] = p2; out.d[st][2][d] = pk_bf16(a, b);
+        keep(out.d[st][0][d], out.d[st][1][d], out.d[st][2][d]);
+    }
+}
+__device__ __forceinline__ void sigmoid_q16(Tile16& p, int q, float* lsum /*[2]: per sample tile*/) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float sig, l2;
+        lsnf_sigmoid_log2(p.q[q][r], sig, l2);
+        p.q[q][r] = sig; lsum[q & 1] += l2;
+    }
+    keep(p.q[q][0], p.q[q][1], p.q[q][2], p.q[q][3], lsum[q & 1]);
+}
+__device__ __forceinline__ void couple_q16(Tile16& v, const Tile16& t, const Tile16& sig, int q) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v.q[q][r] = (v.q[q][r] + t.q[q][r]) * sig.q[q][r];
+}
+
+template <int NV>
+__device__ __forceinline__ void pin12() {       // 12 MFMAs, NV VALU spread behind them (the first NV % 12 slots carry one more)
+    lsnf_static_for<12>([&](auto mc) {
+        constexpr int m = decltype(mc)::value, V = NV / 12 + (m < NV % 12 ? 1 : 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (V > 0) __builtin_amdgcn_sched_group_barrier(0x402, V, 0);
+    });
+}
+// StepDesc here: acc = output tile, s = its 16-feature half ft, tile = input k-tile, frag as above
+template <class PH, class Fill, class Mid>
+__device__ __forceinline__ void run_phase16(Tile16* acc, const SplitTile16* in, const float* lbuf, int lane, Fill&& fill, Mid&& mid) {
+    const bf16x8* wp = reinterpret_cast<const bf16x8*>(lbuf) + lane;
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 a[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) a[p] = wp[(PH::at(0).frag + p) * 64];
+    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+    lsnf_static_for<PH::N>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr StepDesc d = PH::at(i);
+        if constexpr (i == PH::MID) { mid(); __builtin_amdgcn_sched_barrier(0); }
+        bf16x8 na[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) na[p] = a[p];
+        if constexpr (i + 1 < PH::N) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) na[p] = wp[(PH::at(i + 1).frag + p) * 64];
+        }
+#ifndef LSNF_ABL_NOFILL
+        fill(ic);
+#endif
+        const SplitTile16& x = in[d.tile];
+#define LSNF_Q_MMA(WI, XI) \
+        acc[d.acc].q[2 * d.s + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[WI], __builtin_bit_cast(bf16x8, u32x4{x.d[0][XI][0], x.d[0][XI][1], x.d[0][XI][2], x.d[0][XI][3]}), acc[d.acc].q[2 * d.s + 0], 0, 0, 0); \
+        acc[d.acc].q[2 * d.s + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[WI], __builtin_bit_cast(bf16x8, u32x4{x.d[1][XI][0], x.d[1][XI][1], x.d[1][XI][2], x.d[1][XI][3]}), acc[d.acc].q[2 * d.s + 1], 0, 0, 0);
+#ifdef LSNF_ABL_NOMFMA
+        LSNF_Q_MMA(0, 0)
+#else
+        LSNF_F3_TERMS(LSNF_Q_MMA)
+#endif
+#undef LSNF_Q_MMA
+        if constexpr (i + 1 < PH::N) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        pin12<PH::valu(i)>();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[p] = na[p];
+    });
+}
+
+// ---- phase tables (16 steps = 192 MFMAs out of one 48 KiB buffer); valu(i) = VALU instructions pinned into step i -------------
+// VALU per quad (this file is compiled without packed fp32 math, see the Makefile): split 22, ReLU + split 26, sigmoid / log2 28,
+// coupling 8.  The loop is rotated: S1a of block b+1 carries the END of block b's coupling.
+// S1a: v[0], v[1], natural k order.  Its inputs x[0], x[1] ARE the previous block's v[0], v[1], whose split (S2's input, made
+// under S1b) is simply kept -- no second split; x[2]'s split is finished under steps 0-1, then sigmoid(p1) (2-5), the coupling
+// of x[3] (6-7) and its split (8-11: k-tile 3 starts at step 12) of the previous block
+struct QhS1a {
+    static constexpr int N = 16, MID = 8;
+    static constexpr StepDesc at(int i) { return mkstep<4>((i >> 1) & 1, (i >> 1) & 1, i >> 2, i >> 2, i & 1); }
+    static constexpr int valu(int i) { return i < 2 ? 22 : (i < 6 ? 28 : (i < 8 ? 16 : (i < 12 ? 22 : 0))); }
+};
+// S1b: v[2], v[3]; split v[0], v[1] (S2's input and the next block's x[0], x[1]) under the first eight steps
+struct QhS1b {
+    static constexpr int N = 16, MID = 8;
+    static constexpr StepDesc at(int i) { return mkstep<4>((i >> 1) & 1, (i >> 1) & 1, i >> 2, i >> 2, i & 1); }
+    static constexpr int valu(int i) { return i < 8 ? 22 : 0; }
+};
+// S2 + S3 out of one buffer [h1_0][h1_1][h2_0][h2_1].  S2 n-major (h1[0] is complete after step 3 and is split under h1[1]'s
+// steps 4-7), S3 k-major (h1[1] is split under its k-tile-0 steps 8-11; h2's halves complete at steps 12..15)
+struct QhS23 {
+    static constexpr int N = 16, MID = 8;
+    static constexpr StepDesc at(int i) {
+        if (i < 8) { const int tl = i >> 2, kt = (i >> 1) & 1; return mkstep<2>(tl, tl, kt, kt, i & 1); }
+        const int j = i - 8, kt = j >> 2, tl = (j >> 1) & 1;
+        return mkstep<2>(2 + tl, 2 + tl, 2 + kt, kt, j & 1);
+    }
+    static constexpr int valu(int i) { return (i >= 4 && i < 12) ? 26 : (i >= 13 ? 26 : 0); }
+};
+// S4 out of one buffer [t0][t1][p0][p1]: k-tile 0 of all four tiles first (h2[1]'s split hides there), then k-tile 1 in the
+// order p0, t0, p1, t1
+struct QhS4 {
+    static constexpr int N = 16, MID = 8;
+    static constexpr int torder(int j) { return j == 0 ? 2 : (j == 1 ? 0 : (j == 2 ? 3 : 1)); }     // p0, t0, p1, t1 (buffer tiles)
+    static constexpr StepDesc at(int i) { const int kt = i >> 3, j = (i >> 1) & 3; return mkstep<2>(j, torder(j), kt, kt, i & 1); }
+    //   steps 0-3: relu+split h2[1] | 9-12: sigmoid(p0) | 12-13: coupling of x[2] | 14-15: the first half of its split
+    static constexpr int valu(int i) { return i < 4 ? 26 : (i < 9 ? 0 : (i < 12 ? 28 : (i == 12 ? 36 : (i == 13 ? 24 : 22)))); }
+};
+
+template <int WT, int NWAVES>
+__global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pArgs a) {
+    using C = Fwd3pCfg<WT>;
+    static_assert(WT == 2, "lsnf_fwd3q_kernel: f_width <= 64 instantiation");
+    constexpr int THREADS = 64 * NWAVES;
+    constexpr int HT = 2, NZT = 4, F = C::F;
+    constexpr int SLOT = C::SLOT3;                             // 48 KiB
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* cst = smem;
+    float* const buf0 = smem + a.n_blocks * C::CONST_FLOATS;   // 3 x SLOT
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int n = lane & 15, g = lane >> 4;
+#ifdef LSNF_ABL_NOSTAGGER
+    const bool late = false;
+#else
+    const bool late = NWAVES == 8 && wave >= 4;                // (see lsnf_fwd3p_kernel)
+#endif
+    P_STAMP(0, "s_memtime");
+    P_STAMP(50, "s_memrealtime");
+    const int n_phases = 4 * a.n_blocks;
+    auto phase_src = [&](int k) -> const float* {
+        const float* gb = a.panels3 + (size_t)(k >> 2) * C::BLOCK3;
+        const int j = k & 3;
+        return gb + (j == 0 ? 0 : (j == 1 ? 2 * 4 * F : (j == 2 ? C::OFF3_S2 : C::OFF3_S4)));
+    };
+    auto sync_issue = [&](int k) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (k + 1 < n_phases) issue_kib<48, NWAVES>(phase_src(k + 1), buf0 + ((k + 1) % 3) * SLOT, wave, lane);
+    };
+    issue_kib<48, NWAVES>(phase_src(0), buf0, wave, lane);
+    for (int i = tid; i < a.n_blocks * C::CONST_FLOATS; i += THREADS) cst[i] = a.consts[i];
+
+    const int wbase = (blockIdx.x * NWAVES + wave) * 32;
+    int sample[2], rows[2]; bool live[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) { sample[st] = wbase + 16 * st + n; live[st] = sample[st] < a.B; rows[st] = live[st] ? sample[st] : a.B - 1; }
+
+    // Loop-carried state: xs[0..1] = split of the block input's first half (= the previous block's split v1), xs[2] with the
+    // quads 0, 1 of x[2] split, v[2] = x[2] (fp32, until its split is complete), v[3] = v2[1] BEFORE its coupling, p1 / t1 =
+    // the previous block's pre-sigmoid / shift for it (block 0: p1 = 80, t1 = 0: sigmoid = 1 exactly, log = 0 -- the identity),
+    // lsum = the running sum of log2(1 + exp(-p)) over all blocks (scaled once, in the epilogue)
+    Tile16 v[NZT];
+    SplitTile16 xs[NZT];
+    Tile16 p1, t1;
+    float lsum[2] = {0.0f, 0.0f};
+    {
+        const Tile16 x0 = to_tile16(l16_load_tile<HT>(0, a.z_in, rows, a.nz, a.half, g, a.vec4));
+        const Tile16 x1 = to_tile16(l16_load_tile<HT>(1, a.z_in, rows, a.nz, a.half, g, a.vec4));
+        v[2] = to_tile16(l16_load_tile<HT>(2, a.z_in, rows, a.nz, a.half, g, a.vec4));
+        v[3] = to_tile16(l16_load_tile<HT>(3, a.z_in, rows, a.nz, a.half, g, a.vec4));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { split_q16<false>(x0, q, xs[0]); split_q16<false>(x1, q, xs[1]); }     // (not hidden: once per launch)
+        split_q16<false>(v[2], 0, xs[2]); split_q16<false>(v[2], 1, xs[2]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { p1.q[q][r] = 80.0f; t1.q[q][r] = 0.0f; }
+    }
+    float ell[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) ell[st] = a.objective ? a.objective[rows[st]] : 0.0f;
+    float ss01[2] = {0.0f, 0.0f};
+    sync_issue(0);
+    P_STAMP(1, "s_memtime");
+
+    for (int blk = 0; blk < a.n_blocks; ++blk) {
+        const float* cb = cst + blk * C::CONST_FLOATS;
+        const bool more = blk + 1 < a.n_blocks;
+        const int k0 = 4 * blk;
+        SplitTile16 vh[4];                          // S2+S3 inputs: split v[0], v[1], h1[0], h1[1]
+        SplitTile16 h2s[WT];
+        Tile16 hh[4], tp[4];                        // hh: h1[0], h1[1], h2[0], h2[1];  tp: p0, t0, p1, t1
+        auto mid_sync = [&](int k) { if (late && k + 1 < n_phases) sync_issue(k + 1); };
+
+        if (blk == 1) P_STAMP(10, "s_memtime");
+        // ---- S1a: v[0,1]  (model.py:187; actnorm :244,268 folded); carries the end of the previous block's coupling (:414-418) ----
+        {
+            v[0] = tile16_bias(cb + 0, g); v[1] = tile16_bias(cb + 32, g);
+            if (!late && k0 > 0) sync_issue(k0);
+            run_phase16<QhS1a>(v, xs, buf0 + (k0 % 3) * SLOT, lane, [&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i < 2) split_q16<false>(v[2], 2 + i, xs[2]);                 // x[2]: k-tile 2 starts at step 8
+                else if constexpr (i < 6) sigmoid_q16(p1, i - 2, lsum);
+                else if constexpr (i < 8) { couple_q16(v[3], t1, p1, 2 * (i - 6)); couple_q16(v[3], t1, p1, 2 * (i - 6) + 1); }
+                else if constexpr (i < 12) split_q16<false>(v[3], i - 8, xs[3]);           // x[3]: k-tile 3 starts at step 12
+            }, [&] { mid_sync(k0); });
+        }
+        if (blk == 1) P_STAMP(11, "s_memtime");
+        // ---- S1b: v[2,3]; split v[0], v[1]: S2's input AND the next block's x[0], x[1] ----
+        {
+            v[2] = tile16_bias(cb + 64, g); v[3] = tile16_bias(cb + 96, g);
+            if (!late) sync_issue(k0 + 1);
+            run_phase16<QhS1b>(v + 2, xs, buf0 + ((k0 + 1) % 3) * SLOT, lane, [&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i < 8) split_q16<false>(v[i >> 2], i & 3, vh[i >> 2]);
+            }, [&] { mid_sync(k0 + 1); });
+        }
+        if (blk == 1) P_STAMP(12, "s_memtime");
+        if (!more) {             // last block: the v1 half is final (model.py:422) -- its stores drain under S2..S4
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+                l16_store_tile<HT>(t, from_tile16(v[t]), a.z_out, sample, live, a.nz, a.half, g, a.vec4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ss01[q & 1] += v[t].q[q][r] * v[t].q[q][r];
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) { ell[st] = ell[st] + cb[32 * C::NP + 0]; ell[st] = ell[st] + cb[32 * C::NP + 1]; }
+        // ---- S2 + S3: h1 = relu(actnorm(v1 @ W1)), h2 = relu(actnorm(h1 @ W2))  (model.py:326-328,307-308) ----
+        {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) hh[t] = tile16_bias(cb + 32 * (C::P1 + t), g);
+            if (!late) sync_issue(k0 + 2);
+            run_phase16<QhS23>(hh, vh, buf0 + ((k0 + 2) % 3) * SLOT, lane, [&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i >= 4 && i < 8) split_q16<true>(hh[0], i - 4, vh[2]);      // h1[0] under h1[1]'s steps
+                if constexpr (i >= 8 && i < 12) split_q16<true>(hh[1], i - 8, vh[3]);     // h1[1] under S3's k-tile 0
+                if constexpr (i >= 13) split_q16<true>(hh[2], i - 13, h2s[0]);             // h2[0]: its halves complete after steps 12, 13
+            }, [&] { mid_sync(k0 + 2); });
+        }
+        if (blk == 1) P_STAMP(13, "s_memtime");
+        xs[0] = vh[0]; xs[1] = vh[1];            // v1 is the next block's first half (model.py:422): its split is kept
+        // ---- S4: p0, t0, p1, t1 = fc_zeros(h2), de-interleaved (model.py:347-349,411-413) + coupling (:414-418) ----
+        {
+            constexpr int B4 = C::P1 + C::P2 + C::P3;
+            tp[0] = tile16_bias(cb + 32 * (B4 + HT), g); tp[1] = tile16_bias(cb + 32 * (B4 + 0), g);
+            tp[2] = tile16_bias(cb + 32 * (B4 + HT + 1), g); tp[3] = tile16_bias(cb + 32 * (B4 + 1), g);
+            split_q16<true>(hh[2], 3, h2s[0]);       // (the last quad of h2[0]: exposed, S4's first step needs it)
+            if (!late) sync_issue(k0 + 3);
+            run_phase16<QhS4>(tp, h2s, buf0 + ((k0 + 3) % 3) * SLOT, lane, [&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i < 4) split_q16<true>(hh[3], i, h2s[1]);                    // h2[1] under k-tile 0
+                // k-tile 1: p0's halves are complete after steps 8, 9; t0's after 10, 11; p1's after 12, 13; t1's after 14, 15
+                if constexpr (i >= 9 && i < 13) sigmoid_q16(tp[0], i - 9, lsum);
+                if constexpr (i == 12) couple_q16(v[2], tp[1], tp[0], 0);
+                if constexpr (i == 13) { couple_q16(v[2], tp[1], tp[0], 1); couple_q16(v[2], tp[1], tp[0], 2); couple_q16(v[2], tp[1], tp[0], 3); }
+                if constexpr (i >= 14) split_q16<false>(v[2], i - 14, xs[2]);
+            }, [&] { mid_sync(k0 + 3); });
+            p1 = tp[2]; t1 = tp[3];              // (the rest of the coupling rides under the next block's S1a)
+        }
+        if (blk == 1) P_STAMP(14, "s_memtime");
+    }
+    P_STAMP(40, "s_memtime");
+    // the last block's x[3] (no S1a follows)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { sigmoid_q16(p1, q, lsum); couple_q16(v[3], t1, p1, q); }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) ell[st] = ell[st] + -0.6931471805599453f * l16_group_sum(lsum[st]);
+
+    // ---- epilogue: z_out, logdet, ll = -0.5*sum z^2 + log(2pi) + logdet (train.py:317-319) ----
+    float ss[2] = {ss01[0], ss01[1]};
+#pragma unroll
+    for (int t = HT; t < NZT; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ss[q & 1] += v[t].q[q][r] * v[t].q[q][r];
+        l16_store_tile<HT>(t, from_tile16(v[t]), a.z_out, sample, live, a.nz, a.half, g, a.vec4);
+    }
+    float ll[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        ll[st] = (-0.5f * l16_group_sum(ss[st]) + 1.8378770664093453f) + ell[st];
+        if (live[st] && g == 0) {
+            int smp = sample[st];
+            asm volatile("" : "+v"(smp));
+            a.logdet_out[smp] = ell[st];
+            if (a.ll_out) a.ll_out[smp] = ll[st];
+        }
+    }
+    if (a.stats) {
+        double dl = 0.0, dd = 0.0;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+            if (live[st] && g == 0) { dl += (double)ll[st]; dd += (double)ell[st]; }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { dl += __shfl_xor(dl, o, 64); dd += __shfl_xor(dd, o, 64); }
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(buf0);
+        if (lane == 0) { red[2 * wave] = dl; red[2 * wave + 1] = dd; }
+        __syncthreads();
+        if (tid == 0) {
+            double tl = 0.0, td = 0.0;
+            for (int w = 0; w < NWAVES; ++w) { tl += red[2 * w]; td += red[2 * w + 1]; }
+            lsnf_publish_stats(a.stats, tl, td, a.B);
+        }
+    }
+    P_STAMP(41, "s_memtime");
+    P_STAMP(51, "s_memrealtime");
+}
+
+template <int WT, int NWAVES>
+hipError_t launch_fwd3q_w(const Fwd3pArgs& a, hipStream_t stream) {
+    using C = Fwd3pCfg<WT>;
+    const size_t lds = ((size_t)a.n_blocks * C::CONST_FLOATS + 3 * (size_t)C::SLOT3) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto kern = lsnf_fwd3q_kernel<WT, NWAVES>;
+    static unsigned long long lds_ok = 0;
+    if (hipError_t e = lsnf_allow_big_lds((const void*)kern, &lds_ok); e != hipSuccess) return e;
+    const unsigned grid = (unsigned)((a.B + 32 * NWAVES - 1) / (32 * NWAVES));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NWAVES), lds, stream, a);
+    return hipGetLastError();
+}
+
 template <int WT, int NWAVES>
 hipError_t launch_fwd3p_w(const Fwd3pArgs& a, hipStream_t stream) {
     using C = Fwd3pCfg<WT>;
@@ -424,5 +789,10 @@ hipError_t lsnf_launch_forward3p(const LsnfGeo& g, const float* plan, int first_
       if (!g_lsnf_stamps) { if (hipMalloc(&g_lsnf_stamps, sizeof(unsigned long long) * 64 * 4 * 4096) != hipSuccess) g_lsnf_stamps = nullptr; }
       a.stamps = g_lsnf_stamps; }
 #endif
+    const char* q16 = getenv("LSNF_PIPE16");               // experiment knob (read per call): the 16x16x32 form of the pipeline
+    if (q16 && atoi(q16) != 0) {
+        a.panels3 = plan + g.off_f3b_panels + (size_t)first_block * g.f3_block_floats;
+        return B > 128 * 256 ? launch_fwd3q_w<2, 8>(a, stream) : launch_fwd3q_w<2, 4>(a, stream);
+    }
     return B > 128 * 256 ? launch_fwd3p_w<2, 8>(a, stream) : launch_fwd3p_w<2, 4>(a, stream);
 }

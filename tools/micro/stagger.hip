@@ -171,7 +171,14 @@ template <int NM, int PAIRS, int NOP> void gaps(int iters) {
     snprintf(nm, sizeof nm, "staggered, s_nop %d gaps, setprio in MFMA", NOP); run<30 + NOP, NM, PAIRS>(nm, iters);
     snprintf(nm, sizeof nm, "in phase, s_nop %d gaps, setprio in MFMA", NOP);  run<70 + NOP, NM, PAIRS>(nm, iters);
 }
+template <int NM, int PAIRS> void ratio(int iters) {       // in-wave interleave at different VALU : MFMA ratios (14 VALU per pair)
+    run<0, NM, PAIRS>("MFMA only", iters);
+    run<1, NM, PAIRS>("VALU only", iters);
+    run<2, NM, PAIRS>("in phase [bar, MFMA, VALU]", iters);
+    run<5, NM, PAIRS>("interleaved inside every wave", iters);
+}
 int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == 'r') { ratio<96, 4>(200); ratio<96, 7>(200); ratio<96, 10>(200); ratio<96, 14>(200); return 0; }
     if (argc > 1) {      // the gap experiment
         gaps<96, 16, 0>(200); gaps<96, 16, 1>(200); gaps<96, 16, 3>(200); gaps<96, 16, 5>(200); gaps<96, 16, 7>(200); gaps<96, 16, 9>(200); gaps<96, 16, 11>(200);
         return 0;

@@ -13,7 +13,10 @@ out = (torch.empty_like(z), torch.empty(z.shape[0], device=dev), torch.empty(z.s
 lib = lsnf_amd.load_library()
 lib.lsnf_debug_stamps.restype = ctypes.c_void_p
 hip = ctypes.CDLL("libamdhip64.so")
-lsnf_amd.flow.set_math_mode(lsnf_amd.flow.MATH_BF16X3)
+which = sys.argv[1] if len(sys.argv) > 1 else "p"          # p: lsnf_fwd3p_kernel (32x32x16), q: lsnf_fwd3q_kernel (16x16x32)
+os.environ["LSNF_PIPE16"] = "1" if which == "q" else "0"
+lsnf_amd.flow.set_math_mode(lsnf_amd.flow.MATH_BF16X3_PIPE)
+lsnf_amd.flow.set_small_batch_max(0)
 t0 = time.perf_counter(); n = 0
 while time.perf_counter() - t0 < 2.5:
     for _ in range(200):
@@ -24,7 +27,7 @@ hip.hipMemcpy(buf, ctypes.c_void_p(lib.lsnf_debug_stamps()), ctypes.c_size_t(204
 s = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 64).astype(np.int64)
 cyc = (s[:, 41] - s[:, 0]).astype(np.float64); rt = (s[:, 51] - s[:, 50]).astype(np.float64)
 ok = rt > 0
-print(f"lsnf_fwd3p_kernel after {n} launches: in-kernel clock median {np.median(cyc[ok] / rt[ok]) * 0.1:.3f} GHz; wave lifetime "
+print(f"lsnf_fwd3{which}_kernel after {n} launches: in-kernel clock median {np.median(cyc[ok] / rt[ok]) * 0.1:.3f} GHz; wave lifetime "
       f"median {np.median(rt[ok]) / 100:.1f} us = {np.median(cyc[ok]):.0f} cycles")
 print(f"  prologue (row loads, first split, barrier 0) {np.median((s[:, 1] - s[:, 0])[ok]):9.0f} cycles")
 print(f"  block 0                               {np.median((s[:, 10] - s[:, 1])[ok]):9.0f}")
