@@ -76,16 +76,20 @@ int lsnf_set_small_batch_max(int rows);
 /* Arithmetic of the GEMMs.  Affects the forward, the backward and the reverse (both kernel families); the parameter-
  * gradient contraction over the batch is fp32 MFMA in every mode:
  *   LSNF_MATH_BF16X3 : (default) both operands split error-free into three bf16 terms (3 x 8 = 24 significand bits,
- *                      fp32's exponent range), six bf16 MFMAs per product with fp32 accumulation (csrc/lsnf_fwd3.hip, on
- *                      v_mfma_f32_16x16x32_bf16).  Same accuracy class as fp32 MFMA (dropped terms <= 2^-26 |w||x|);
- *                      results agree with LSNF_MATH_FP32 to fp32 rounding, not bit for bit.
+ *                      fp32's exponent range), six bf16 MFMAs per product with fp32 accumulation, on
+ *                      v_mfma_f32_16x16x32_bf16.  Same accuracy class as fp32 MFMA (dropped terms <= 2^-26 |w||x|);
+ *                      results agree with LSNF_MATH_FP32 to fp32 rounding, not bit for bit.  Throughput forward calls
+ *                      without stash / parameter-gradient dump at nz in 66..128, f_width <= 64 run lsnf_fwd3q_kernel
+ *                      (csrc/lsnf_fwd3p.hip: operand split and coupling epilogue software-pipelined between the MFMAs),
+ *                      everything else csrc/lsnf_fwd3.hip (separate split / MFMA / epilogue phases).
+ *   LSNF_MATH_BF16X3_PHASED : as LSNF_MATH_BF16X3 with every throughput forward on csrc/lsnf_fwd3.hip (comparison, tests).
  *   LSNF_MATH_FP32   : fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere.
  *   LSNF_MATH_BF16X3_32 : the bf16x3 scheme on v_mfma_f32_32x32x16_bf16 in the throughput forward (kept for comparison:
  *                      that shape sustains a lower clock on real data, ~8 % slower); latency forward as LSNF_MATH_FP32.
  *   LSNF_MATH_BF16X3_PIPE : as LSNF_MATH_BF16X3, the throughput forward (calls without stash / block outputs, nz > 64,
- *                      width <= 64) on csrc/lsnf_fwd3p.hip: 32x32x16 MFMAs with the operand split and the coupling
- *                      epilogue software-pipelined between them.  Fewer cycles, lower sustained clock: measured equal
- *                      or slower than LSNF_MATH_BF16X3; kept as the reference point for that finding.
+ *                      width <= 64) on the 32x32x16 form of that pipeline (lsnf_fwd3p_kernel).  Fewer cycles, but the chip
+ *                      sustains a ~12 % lower clock under that MFMA shape: measured slower than LSNF_MATH_BF16X3
+ *                      (DESIGN.md section 5); kept as the reference point for that finding.
  *   LSNF_MATH_FP16X2 : (opt-in; NARROWER than the reference's fp32: 11 + 11 operand bits) throughput forward and reverse
  *                      with both operands split into two fp16 terms, three fp16 MFMAs per product (csrc/lsnf_fwd2h.hip;
  *                      dropped terms <= 2^-22 |w||x|; operands below 2^-3 in magnitude additionally carry an ABSOLUTE
@@ -104,6 +108,7 @@ int lsnf_set_small_batch_max(int rows);
 #define LSNF_MATH_BF16X3_32 2
 #define LSNF_MATH_FP16X2 3
 #define LSNF_MATH_BF16X3_PIPE 4
+#define LSNF_MATH_BF16X3_PHASED 5
 #define LSNF_MATH_DEFAULT LSNF_MATH_BF16X3
 int lsnf_set_math_mode(int mode);
 

@@ -26,6 +26,9 @@ hipError_t lsnf_launch_forward3(const LsnfGeo& g, const float* plan, int first_b
                                 const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                 float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
                                 int shape16, int fixup, hipStream_t stream, float* hdump = nullptr);
+hipError_t lsnf_launch_forward3q(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
+                                 const float* z_in, const float* objective, float* z_out, float* logdet_out,
+                                 float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4, hipStream_t stream);
 hipError_t lsnf_launch_forward3p(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                  const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                  float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4, hipStream_t stream);
@@ -100,7 +103,7 @@ int row_vector_width(const LsnfGeo& g, std::initializer_list<const void*> rows) 
 }
 bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
 
-// arithmetic of the GEMMs (LSNF_MATH=fp32|bf16x3|bf16x3_32|bf16x3_pipe|fp16x2 overrides the default).  The two knobs are
+// arithmetic of the GEMMs (LSNF_MATH=fp32|bf16x3|bf16x3_phased|bf16x3_32|bf16x3_pipe|fp16x2 overrides the default).  The two knobs are
 // process-wide settings read by every call: atomics, so that a setter on one thread and a launch on another do not race
 // (a launch sees the old or the new value, never a torn one).
 std::atomic<int> g_math{-1};
@@ -109,7 +112,7 @@ int math_mode() {
     if (m < 0) {
         const char* e = getenv("LSNF_MATH");
         m = (e && !strcmp(e, "bf16x3")) ? LSNF_MATH_BF16X3 : (e && !strcmp(e, "bf16x3_32")) ? LSNF_MATH_BF16X3_32
-          : (e && !strcmp(e, "bf16x3_pipe")) ? LSNF_MATH_BF16X3_PIPE
+          : (e && !strcmp(e, "bf16x3_pipe")) ? LSNF_MATH_BF16X3_PIPE : (e && !strcmp(e, "bf16x3_phased")) ? LSNF_MATH_BF16X3_PHASED
           : (e && !strcmp(e, "fp16x2")) ? LSNF_MATH_FP16X2 : (e && !strcmp(e, "fp32")) ? LSNF_MATH_FP32 : LSNF_MATH_DEFAULT;
         int expected = -1;
         g_math.compare_exchange_strong(expected, m, std::memory_order_relaxed);
@@ -141,7 +144,7 @@ int small_batch_max() {
     return math_mode() == LSNF_MATH_FP16X2 ? 12288 : LSNF_SMALL_MAX_DEFAULT;
 }
 // modes whose latency / backward / reverse kernels are the bf16x3 "L16" ones
-bool l16_math() { const int m = math_mode(); return m == LSNF_MATH_BF16X3 || m == LSNF_MATH_FP16X2 || m == LSNF_MATH_BF16X3_PIPE; }
+bool l16_math() { const int m = math_mode(); return m == LSNF_MATH_BF16X3 || m == LSNF_MATH_FP16X2 || m == LSNF_MATH_BF16X3_PIPE || m == LSNF_MATH_BF16X3_PHASED; }
 
 int geo_or_fail(LsnfGeo* g, int nz, int width, int depth, int coupling) {
     if (lsnf_geo_init(g, nz, width, depth, coupling))
@@ -165,7 +168,7 @@ int lsnf_set_small_batch_max(int rows) {
 int lsnf_set_math_mode(int mode) {
     const int prev = math_mode();
     if (mode == LSNF_MATH_FP32 || mode == LSNF_MATH_BF16X3 || mode == LSNF_MATH_BF16X3_32 || mode == LSNF_MATH_FP16X2 ||
-        mode == LSNF_MATH_BF16X3_PIPE)
+        mode == LSNF_MATH_BF16X3_PIPE || mode == LSNF_MATH_BF16X3_PHASED)
         g_math.store(mode, std::memory_order_relaxed);
     return prev;
 }
@@ -244,7 +247,7 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
     // crossover, throughput kernel (128 rows per workgroup, weights shared through LDS) above it
     hipError_t e;
     const int math = math_mode();
-    const bool split = math == LSNF_MATH_BF16X3 || math == LSNF_MATH_BF16X3_32 || math == LSNF_MATH_BF16X3_PIPE;
+    const bool split = math == LSNF_MATH_BF16X3 || math == LSNF_MATH_BF16X3_32 || math == LSNF_MATH_BF16X3_PIPE || math == LSNF_MATH_BF16X3_PHASED;
     if (B <= small_batch_max()) {
         e = hipErrorInvalidValue;
         if (l16_math())                           // latency forward on the bf16 pipe: 16-sample workgroups (lsnf_small3_fwd.hip)
@@ -268,6 +271,9 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
                 e = lsnf_launch_forward3(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
                                          z_saved, act_saved, nullptr, vec4, 1, /*fixup=*/1, (hipStream_t)stream, hdump);
         }
+        if (math == LSNF_MATH_BF16X3 && !hdump)        // vector work software-pipelined under 16x16x32 MFMAs (lsnf_fwd3p.hip, lsnf_fwd3q_kernel)
+            e = lsnf_launch_forward3q(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
+                                      z_saved, act_saved, stats, vec4, (hipStream_t)stream);
         if (math == LSNF_MATH_BF16X3_PIPE && !hdump)   // the 32x32x16 kernel with its vector work pipelined under the MFMAs (lsnf_fwd3p.hip)
             e = lsnf_launch_forward3p(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
                                       z_saved, act_saved, stats, vec4, (hipStream_t)stream);

@@ -421,15 +421,23 @@ __device__ __forceinline__ f32x16 from_tile16(const Tile16& t) {
         for (int r = 0; r < 4; ++r) x[4 * q + r] = t.q[q][r];
     return x;
 }
-__device__ __forceinline__ Tile16 tile16_bias(const float* cst, int g) {
-    Tile16 t;
+// The bias of an output tile (its 2 x 4 values per lane) is the C operand of the FIRST MFMA of each accumulator chain: both
+// sample tiles start from the same registers, nothing is copied (an initialised accumulator pair would cost 8 v_mov per tile)
+struct Bias16 { f32x4v b[2]; };
+__device__ __forceinline__ Bias16 bias16(const float* cst, int g) {
+    Bias16 t;
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(cst + (g & 1) * 16 + 4 * (2 * ft + (g >> 1)));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { t.q[2 * ft][r] = v[r]; t.q[2 * ft + 1][r] = v[r]; }
+        for (int r = 0; r < 4; ++r) t.b[ft][r] = v[r];
     }
     return t;
+}
+template <class PH> constexpr bool first_touch(int i) {       // is step i the first one on its (accumulator, ft)?
+    for (int j = 0; j < i; ++j)
+        if (PH::at(j).acc == PH::at(i).acc && PH::at(j).s == PH::at(i).s) return false;
+    return true;
 }
 // quad q = 2*ft + st of a tile (optionally through ReLU) -> dwords 2*ft, 2*ft + 1 of sample tile st: 18 (22) VALU
 template <bool RELU>
@@ -472,7 +480,7 @@ __device__ __forceinline__ void pin12() {       // 12 MFMAs, NV VALU spread behi
 }
 // StepDesc here: acc = output tile, s = its 16-feature half ft, tile = input k-tile, frag as above
 template <class PH, class Fill, class Mid>
-__device__ __forceinline__ void run_phase16(Tile16* acc, const SplitTile16* in, const float* lbuf, int lane, Fill&& fill, Mid&& mid) {
+__device__ __forceinline__ void run_phase16(Tile16* acc, const Bias16* bias, const SplitTile16* in, const float* lbuf, int lane, Fill&& fill, Mid&& mid) {
     const bf16x8* wp = reinterpret_cast<const bf16x8*>(lbuf) + lane;
     __builtin_amdgcn_sched_barrier(0);
     bf16x8 a[3];
@@ -494,9 +502,10 @@ __device__ __forceinline__ void run_phase16(Tile16* acc, const SplitTile16* in, 
         fill(ic);
 #endif
         const SplitTile16& x = in[d.tile];
+        constexpr bool first = first_touch<PH>(i);
 #define LSNF_Q_MMA(WI, XI) \
-        acc[d.acc].q[2 * d.s + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[WI], __builtin_bit_cast(bf16x8, u32x4{x.d[0][XI][0], x.d[0][XI][1], x.d[0][XI][2], x.d[0][XI][3]}), acc[d.acc].q[2 * d.s + 0], 0, 0, 0); \
-        acc[d.acc].q[2 * d.s + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[WI], __builtin_bit_cast(bf16x8, u32x4{x.d[1][XI][0], x.d[1][XI][1], x.d[1][XI][2], x.d[1][XI][3]}), acc[d.acc].q[2 * d.s + 1], 0, 0, 0);
+        acc[d.acc].q[2 * d.s + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[WI], __builtin_bit_cast(bf16x8, u32x4{x.d[0][XI][0], x.d[0][XI][1], x.d[0][XI][2], x.d[0][XI][3]}), (first && WI == 2 && XI == 0) ? bias[d.acc].b[d.s] : acc[d.acc].q[2 * d.s + 0], 0, 0, 0); \
+        acc[d.acc].q[2 * d.s + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[WI], __builtin_bit_cast(bf16x8, u32x4{x.d[1][XI][0], x.d[1][XI][1], x.d[1][XI][2], x.d[1][XI][3]}), (first && WI == 2 && XI == 0) ? bias[d.acc].b[d.s] : acc[d.acc].q[2 * d.s + 1], 0, 0, 0);
 #ifdef LSNF_ABL_NOMFMA
         LSNF_Q_MMA(0, 0)
 #else
@@ -522,11 +531,11 @@ struct QhS1a {
     static constexpr StepDesc at(int i) { return mkstep<4>((i >> 1) & 1, (i >> 1) & 1, i >> 2, i >> 2, i & 1); }
     static constexpr int valu(int i) { return i < 2 ? 22 : (i < 6 ? 28 : (i < 8 ? 16 : (i < 12 ? 22 : 0))); }
 };
-// S1b: v[2], v[3]; split v[0], v[1] (S2's input and the next block's x[0], x[1]) under the first eight steps
+// S1b: v[2], v[3]; split v[0], v[1] (S2's input and the next block's x[0], x[1]) under the last eight steps
 struct QhS1b {
     static constexpr int N = 16, MID = 8;
     static constexpr StepDesc at(int i) { return mkstep<4>((i >> 1) & 1, (i >> 1) & 1, i >> 2, i >> 2, i & 1); }
-    static constexpr int valu(int i) { return i < 8 ? 22 : 0; }
+    static constexpr int valu(int i) { return i >= 8 ? 22 : 0; }
 };
 // S2 + S3 out of one buffer [h1_0][h1_1][h2_0][h2_1].  S2 n-major (h1[0] is complete after step 3 and is split under h1[1]'s
 // steps 4-7), S3 k-major (h1[1] is split under its k-tile-0 steps 8-11; h2's halves complete at steps 12..15)
@@ -558,16 +567,12 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
     constexpr int SLOT = C::SLOT3;                             // 48 KiB
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* cst = smem;
-    float* const buf0 = smem + a.n_blocks * C::CONST_FLOATS;   // 3 x SLOT
+    float* const buf0 = smem + a.n_blocks * C::CONST_FLOATS;   // 2 x SLOT
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int n = lane & 15, g = lane >> 4;
-#ifdef LSNF_ABL_NOSTAGGER
-    const bool late = false;
-#else
-    const bool late = NWAVES == 8 && wave >= 4;                // (see lsnf_fwd3p_kernel)
-#endif
+    // (no half-a-phase stagger of waves 4-7 here: measured 3 % slower in this kernel, tools/stamps_fwd3p.py -- so two weight buffers)
     P_STAMP(0, "s_memtime");
     P_STAMP(50, "s_memrealtime");
     const int n_phases = 4 * a.n_blocks;
@@ -579,7 +584,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
     auto sync_issue = [&](int k) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (k + 1 < n_phases) issue_kib<48, NWAVES>(phase_src(k + 1), buf0 + ((k + 1) % 3) * SLOT, wave, lane);
+        if (k + 1 < n_phases) issue_kib<48, NWAVES>(phase_src(k + 1), buf0 + ((k + 1) & 1) * SLOT, wave, lane);
     };
     issue_kib<48, NWAVES>(phase_src(0), buf0, wave, lane);
     for (int i = tid; i < a.n_blocks * C::CONST_FLOATS; i += THREADS) cst[i] = a.consts[i];
@@ -624,30 +629,29 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
         SplitTile16 vh[4];                          // S2+S3 inputs: split v[0], v[1], h1[0], h1[1]
         SplitTile16 h2s[WT];
         Tile16 hh[4], tp[4];                        // hh: h1[0], h1[1], h2[0], h2[1];  tp: p0, t0, p1, t1
-        auto mid_sync = [&](int k) { if (late && k + 1 < n_phases) sync_issue(k + 1); };
 
         if (blk == 1) P_STAMP(10, "s_memtime");
         // ---- S1a: v[0,1]  (model.py:187; actnorm :244,268 folded); carries the end of the previous block's coupling (:414-418) ----
         {
-            v[0] = tile16_bias(cb + 0, g); v[1] = tile16_bias(cb + 32, g);
-            if (!late && k0 > 0) sync_issue(k0);
-            run_phase16<QhS1a>(v, xs, buf0 + (k0 % 3) * SLOT, lane, [&](auto ic) {
+            const Bias16 bv[2] = {bias16(cb + 0, g), bias16(cb + 32, g)};
+            if (k0 > 0) sync_issue(k0);
+            run_phase16<QhS1a>(v, bv, xs, buf0 + (k0 & 1) * SLOT, lane, [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 if constexpr (i < 2) split_q16<false>(v[2], 2 + i, xs[2]);                 // x[2]: k-tile 2 starts at step 8
                 else if constexpr (i < 6) sigmoid_q16(p1, i - 2, lsum);
                 else if constexpr (i < 8) { couple_q16(v[3], t1, p1, 2 * (i - 6)); couple_q16(v[3], t1, p1, 2 * (i - 6) + 1); }
                 else if constexpr (i < 12) split_q16<false>(v[3], i - 8, xs[3]);           // x[3]: k-tile 3 starts at step 12
-            }, [&] { mid_sync(k0); });
+            }, [] {});
         }
         if (blk == 1) P_STAMP(11, "s_memtime");
         // ---- S1b: v[2,3]; split v[0], v[1]: S2's input AND the next block's x[0], x[1] ----
         {
-            v[2] = tile16_bias(cb + 64, g); v[3] = tile16_bias(cb + 96, g);
-            if (!late) sync_issue(k0 + 1);
-            run_phase16<QhS1b>(v + 2, xs, buf0 + ((k0 + 1) % 3) * SLOT, lane, [&](auto ic) {
+            const Bias16 bv[2] = {bias16(cb + 64, g), bias16(cb + 96, g)};
+            sync_issue(k0 + 1);
+            run_phase16<QhS1b>(v + 2, bv, xs, buf0 + ((k0 + 1) & 1) * SLOT, lane, [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                if constexpr (i < 8) split_q16<false>(v[i >> 2], i & 3, vh[i >> 2]);
-            }, [&] { mid_sync(k0 + 1); });
+                if constexpr (i >= 8) split_q16<false>(v[(i - 8) >> 2], i & 3, vh[(i - 8) >> 2]);    // (xs[0], xs[1] are dead by now: k order)
+            }, [] {});
         }
         if (blk == 1) P_STAMP(12, "s_memtime");
         if (!more) {             // last block: the v1 half is final (model.py:422) -- its stores drain under S2..S4
@@ -664,26 +668,24 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
         for (int st = 0; st < 2; ++st) { ell[st] = ell[st] + cb[32 * C::NP + 0]; ell[st] = ell[st] + cb[32 * C::NP + 1]; }
         // ---- S2 + S3: h1 = relu(actnorm(v1 @ W1)), h2 = relu(actnorm(h1 @ W2))  (model.py:326-328,307-308) ----
         {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) hh[t] = tile16_bias(cb + 32 * (C::P1 + t), g);
-            if (!late) sync_issue(k0 + 2);
-            run_phase16<QhS23>(hh, vh, buf0 + ((k0 + 2) % 3) * SLOT, lane, [&](auto ic) {
+            const Bias16 bv[4] = {bias16(cb + 32 * (C::P1 + 0), g), bias16(cb + 32 * (C::P1 + 1), g), bias16(cb + 32 * (C::P1 + 2), g), bias16(cb + 32 * (C::P1 + 3), g)};
+            sync_issue(k0 + 2);
+            run_phase16<QhS23>(hh, bv, vh, buf0 + ((k0 + 2) & 1) * SLOT, lane, [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 if constexpr (i >= 4 && i < 8) split_q16<true>(hh[0], i - 4, vh[2]);      // h1[0] under h1[1]'s steps
                 if constexpr (i >= 8 && i < 12) split_q16<true>(hh[1], i - 8, vh[3]);     // h1[1] under S3's k-tile 0
                 if constexpr (i >= 13) split_q16<true>(hh[2], i - 13, h2s[0]);             // h2[0]: its halves complete after steps 12, 13
-            }, [&] { mid_sync(k0 + 2); });
+            }, [] {});
         }
         if (blk == 1) P_STAMP(13, "s_memtime");
         xs[0] = vh[0]; xs[1] = vh[1];            // v1 is the next block's first half (model.py:422): its split is kept
         // ---- S4: p0, t0, p1, t1 = fc_zeros(h2), de-interleaved (model.py:347-349,411-413) + coupling (:414-418) ----
         {
             constexpr int B4 = C::P1 + C::P2 + C::P3;
-            tp[0] = tile16_bias(cb + 32 * (B4 + HT), g); tp[1] = tile16_bias(cb + 32 * (B4 + 0), g);
-            tp[2] = tile16_bias(cb + 32 * (B4 + HT + 1), g); tp[3] = tile16_bias(cb + 32 * (B4 + 1), g);
+            const Bias16 bv[4] = {bias16(cb + 32 * (B4 + HT), g), bias16(cb + 32 * (B4 + 0), g), bias16(cb + 32 * (B4 + HT + 1), g), bias16(cb + 32 * (B4 + 1), g)};
             split_q16<true>(hh[2], 3, h2s[0]);       // (the last quad of h2[0]: exposed, S4's first step needs it)
-            if (!late) sync_issue(k0 + 3);
-            run_phase16<QhS4>(tp, h2s, buf0 + ((k0 + 3) % 3) * SLOT, lane, [&](auto ic) {
+            sync_issue(k0 + 3);
+            run_phase16<QhS4>(tp, bv, h2s, buf0 + ((k0 + 3) & 1) * SLOT, lane, [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 if constexpr (i < 4) split_q16<true>(hh[3], i, h2s[1]);                    // h2[1] under k-tile 0
                 // k-tile 1: p0's halves are complete after steps 8, 9; t0's after 10, 11; p1's after 12, 13; t1's after 14, 15
@@ -691,7 +693,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
                 if constexpr (i == 12) couple_q16(v[2], tp[1], tp[0], 0);
                 if constexpr (i == 13) { couple_q16(v[2], tp[1], tp[0], 1); couple_q16(v[2], tp[1], tp[0], 2); couple_q16(v[2], tp[1], tp[0], 3); }
                 if constexpr (i >= 14) split_q16<false>(v[2], i - 14, xs[2]);
-            }, [&] { mid_sync(k0 + 3); });
+            }, [] {});
             p1 = tp[2]; t1 = tp[3];              // (the rest of the coupling rides under the next block's S1a)
         }
         if (blk == 1) P_STAMP(14, "s_memtime");
@@ -748,7 +750,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
 template <int WT, int NWAVES>
 hipError_t launch_fwd3q_w(const Fwd3pArgs& a, hipStream_t stream) {
     using C = Fwd3pCfg<WT>;
-    const size_t lds = ((size_t)a.n_blocks * C::CONST_FLOATS + 3 * (size_t)C::SLOT3) * sizeof(float);
+    const size_t lds = ((size_t)a.n_blocks * C::CONST_FLOATS + 2 * (size_t)C::SLOT3) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = lsnf_fwd3q_kernel<WT, NWAVES>;
     static unsigned long long lds_ok = 0;
@@ -789,10 +791,25 @@ hipError_t lsnf_launch_forward3p(const LsnfGeo& g, const float* plan, int first_
       if (!g_lsnf_stamps) { if (hipMalloc(&g_lsnf_stamps, sizeof(unsigned long long) * 64 * 4 * 4096) != hipSuccess) g_lsnf_stamps = nullptr; }
       a.stamps = g_lsnf_stamps; }
 #endif
-    const char* q16 = getenv("LSNF_PIPE16");               // experiment knob (read per call): the 16x16x32 form of the pipeline
-    if (q16 && atoi(q16) != 0) {
-        a.panels3 = plan + g.off_f3b_panels + (size_t)first_block * g.f3_block_floats;
-        return B > 128 * 256 ? launch_fwd3q_w<2, 8>(a, stream) : launch_fwd3q_w<2, 4>(a, stream);
-    }
     return B > 128 * 256 ? launch_fwd3p_w<2, 8>(a, stream) : launch_fwd3p_w<2, 4>(a, stream);
+}
+
+// the 16x16x32 form (lsnf_fwd3q_kernel): the default throughput forward of LSNF_MATH_BF16X3 for calls it covers (nz in 66..128,
+// f_width <= 64, no stash / parameter-gradient dump); hipErrorInvalidValue = not covered, the caller falls back to lsnf_fwd3.hip
+hipError_t lsnf_launch_forward3q(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
+                                 const float* z_in, const float* objective, float* z_out, float* logdet_out,
+                                 float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4, hipStream_t stream) {
+    if (g.HT != 2 || g.WT != 2 || z_saved != nullptr || act_saved != nullptr) return hipErrorInvalidValue;
+    Fwd3pArgs a;
+    a.consts = plan + g.off_fwd_const + (size_t)first_block * g.fwd_const_floats;
+    a.panels3 = plan + g.off_f3b_panels + (size_t)first_block * g.f3_block_floats;
+    a.z_in = z_in; a.objective = objective; a.z_out = z_out; a.logdet_out = logdet_out; a.ll_out = ll_out;
+    a.B = B; a.nz = g.nz; a.half = g.half; a.n_blocks = n_blocks; a.vec4 = vec4; a.stats = stats;
+    a.stamps = nullptr;
+#ifdef LSNF_STAMPS
+    { extern unsigned long long* g_lsnf_stamps;
+      if (!g_lsnf_stamps) { if (hipMalloc(&g_lsnf_stamps, sizeof(unsigned long long) * 64 * 4 * 4096) != hipSuccess) g_lsnf_stamps = nullptr; }
+      a.stamps = g_lsnf_stamps; }
+#endif
+    return B > 128 * 256 ? launch_fwd3q_w<2, 8>(a, stream) : launch_fwd3q_w<2, 4>(a, stream);
 }

@@ -96,7 +96,7 @@ def test_forward_vs_oracle_ragged(lsnf, kernels, gpu_device, nz, width, B):
     assert (z1.cpu() - z1r).abs().max().item() <= Z_ABS * max(1.0, z1r.abs().max().item())
 
 
-@pytest.mark.parametrize("math", ["fp32", "bf16x3", "bf16x3_32", "bf16x3_pipe", "fp16x2"])
+@pytest.mark.parametrize("math", ["fp32", "bf16x3", "bf16x3_phased", "bf16x3_32", "bf16x3_pipe", "fp16x2"])
 def test_full_size_properties(lsnf, gpu_device, math):
     """BASELINE.json's full size (nz=128, w=64, B=65536), both arithmetic modes: size-independent properties.
     (a) row independence: the first 4096 rows of the big launch equal a 4096-row launch bit for bit;
@@ -109,7 +109,7 @@ def test_full_size_properties(lsnf, gpu_device, math):
     zd = z.to(gpu_device)
     prev = lsnf.flow.set_small_batch_max(8192)
     prev_math = lsnf.flow.set_math_mode({"fp32": lsnf.flow.MATH_FP32, "bf16x3": lsnf.flow.MATH_BF16X3,
-                                         "bf16x3_32": lsnf.flow.MATH_BF16X3_32, "bf16x3_pipe": lsnf.flow.MATH_BF16X3_PIPE,
+                                         "bf16x3_phased": lsnf.flow.MATH_BF16X3_PHASED, "bf16x3_32": lsnf.flow.MATH_BF16X3_32, "bf16x3_pipe": lsnf.flow.MATH_BF16X3_PIPE,
                                          "fp16x2": lsnf.flow.MATH_FP16X2}[math])
     z1, ld, ll, _ = lsnf.forward(plan, zd)                                   # throughput kernel
     z1s, lds, lls, _ = lsnf.forward(plan, zd[:16384].contiguous())           # throughput kernel, fewer rows
@@ -142,7 +142,7 @@ def test_split_bf16_is_fp32_faithful(lsnf, gpu_device, name):
     prev = lsnf.flow.set_small_batch_max(0)
     err = {}
     for mode, tag in ((lsnf.flow.MATH_FP32, "fp32"), (lsnf.flow.MATH_BF16X3, "bf16x3"), (lsnf.flow.MATH_BF16X3_32, "bf16x3_32"),
-                      (lsnf.flow.MATH_BF16X3_PIPE, "bf16x3_pipe"), (lsnf.flow.MATH_FP16X2, "fp16x2")):
+                      (lsnf.flow.MATH_BF16X3_PIPE, "bf16x3_pipe"), (lsnf.flow.MATH_BF16X3_PHASED, "bf16x3_phased"), (lsnf.flow.MATH_FP16X2, "fp16x2")):
         prev_math = lsnf.flow.set_math_mode(mode)
         _, _, ll, _ = lsnf.forward(plan, z.to(gpu_device))
         lsnf.flow.set_math_mode(prev_math)
@@ -150,7 +150,7 @@ def test_split_bf16_is_fp32_faithful(lsnf, gpu_device, name):
     lsnf.flow.set_small_batch_max(prev)
     print(name, err)
     assert max(err.values()) <= 2e-6, err
-    assert max(err["bf16x3"], err["bf16x3_32"], err["bf16x3_pipe"]) <= 2.0 * err["fp32"] + 1e-7, err
+    assert max(err["bf16x3"], err["bf16x3_phased"], err["bf16x3_32"], err["bf16x3_pipe"]) <= 2.0 * err["fp32"] + 1e-7, err
     # the two-way fp16 split (lsnf_fwd2h.hip) drops terms of 2^-22 |w||x|: same class, slightly looser bound
     assert err["fp16x2"] <= 3.0 * err["fp32"] + 1e-7, err
 
@@ -165,7 +165,7 @@ def _wg_rows(row, B):
 def test_fp16_split_range_guard(lsnf, gpu_device):
     """LSNF_MATH_FP16X2 (opt-in) has fp16's exponent range.  A wave that meets an operand (or a folded weight) at or beyond
     65504 flags its first logdet element, and the bf16x3 pass queued behind the launch recomputes the workgroups that carry
-    a flag: their rows are then bit-for-bit those of LSNF_MATH_BF16X3 (no inf / NaN, no silently clipped ReLU input), every
+    a flag: their rows are then bit-for-bit those of lsnf_fwd3b_kernel = LSNF_MATH_BF16X3_PHASED (no inf / NaN, no silently clipped ReLU input), every
     other row keeps the fp16 kernel's result.  The flag lives in the launch's own output, so launches of one plan in flight
     on several streams -- or replayed from several graphs -- cannot disturb each other."""
     nz, width, depth, B = 128, 64, 5, 33000
@@ -178,7 +178,7 @@ def test_fp16_split_range_guard(lsnf, gpu_device):
     hot = _wg_rows(12345, B)
     cold = torch.ones(B, dtype=torch.bool, device=gpu_device); cold[hot] = False
     prev_small = lsnf.flow.set_small_batch_max(0)
-    prev = lsnf.flow.set_math_mode(lsnf.flow.MATH_BF16X3)
+    prev = lsnf.flow.set_math_mode(lsnf.flow.MATH_BF16X3_PHASED)
 
     def check_big(o, ref_big, h_small):
         assert torch.isfinite(o[2]).all()
@@ -203,7 +203,7 @@ def test_fp16_split_range_guard(lsnf, gpu_device):
         h_again = lsnf.forward(plan, z.to(gpu_device))                        # nothing sticks: the fp16 kernel's own results again
         for a, b in zip(h_small[:3], h_again[:3]):
             assert torch.equal(a, b)
-        lsnf.flow.set_math_mode(lsnf.flow.MATH_BF16X3)
+        lsnf.flow.set_math_mode(lsnf.flow.MATH_BF16X3_PHASED)
         b_small = lsnf.forward(plan, z.to(gpu_device))
         assert not torch.equal(b_small[2], h_small[2])                        # (the two modes do differ in the last bits)
         assert ((b_small[2] - h_small[2]).abs() / b_small[2].abs().clamp_min(1.0)).max().item() <= 2e-6
@@ -250,7 +250,7 @@ def test_fp16_split_range_guard(lsnf, gpu_device):
             check_big(bufs[0], ref_big, h_small)
             for k in range(3):
                 assert torch.equal(bufs[1][k], h_small[k])
-        lsnf.flow.set_math_mode(lsnf.flow.MATH_BF16X3)
+        lsnf.flow.set_math_mode(lsnf.flow.MATH_BF16X3_PHASED)
         # an activation that leaves the range in mid-stack (block 0 scales by exp(6), |v| ~ 1e5 from |z| ~ 300) with
         # every weight and every input inside it: caught at the stage that consumes it
         q = dict(p)
@@ -268,7 +268,7 @@ def test_fp16_split_range_guard(lsnf, gpu_device):
         keep_rows = torch.ones(B, dtype=torch.bool, device=gpu_device); keep_rows[4321] = False
         assert torch.isfinite(got_mid[2][keep_rows]).all()
         assert ((got_mid[2] - ref_mid[2])[keep_rows].abs() / ref_mid[2][keep_rows].abs().clamp_min(1.0)).max().item() <= 1e-5   # (exp(6)-scaled block: |ll| ~ 3e6)
-        lsnf.flow.set_math_mode(lsnf.flow.MATH_BF16X3)
+        lsnf.flow.set_math_mode(lsnf.flow.MATH_BF16X3_PHASED)
         # folded weights outside fp16's range (actnorm logs = 5 -> exp(15)): prepare marks the plan, every row is recomputed
         q = dict(p)
         k = O.block_prefix(2) + "actnorm.logs"
@@ -336,7 +336,7 @@ def test_split_bf16_dynamic_range(lsnf, gpu_device, z_scale, w_scale):
     plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
     err = {}
     for mode, tag in ((lsnf.flow.MATH_FP32, "fp32"), (lsnf.flow.MATH_BF16X3, "bf16x3"), (lsnf.flow.MATH_BF16X3_32, "bf16x3_32"),
-                      (lsnf.flow.MATH_BF16X3_PIPE, "bf16x3_pipe"), (lsnf.flow.MATH_FP16X2, "fp16x2")):
+                      (lsnf.flow.MATH_BF16X3_PIPE, "bf16x3_pipe"), (lsnf.flow.MATH_BF16X3_PHASED, "bf16x3_phased"), (lsnf.flow.MATH_FP16X2, "fp16x2")):
         prev = lsnf.flow.set_math_mode(mode)
         _, _, ll, _ = lsnf.forward(plan, z.to(gpu_device))
         lsnf.flow.set_math_mode(prev)
@@ -344,5 +344,5 @@ def test_split_bf16_dynamic_range(lsnf, gpu_device, z_scale, w_scale):
         err[tag] = ((ll.cpu()[idx].double() - ll64).abs() / ll64.abs().clamp_min(1.0)).max().item()
     print(z_scale, w_scale, err)
     assert max(err.values()) <= 1e-5, err
-    assert max(err["bf16x3"], err["bf16x3_32"], err["bf16x3_pipe"]) <= 2.0 * err["fp32"] + 1e-7, err
+    assert max(err["bf16x3"], err["bf16x3_phased"], err["bf16x3_32"], err["bf16x3_pipe"]) <= 2.0 * err["fp32"] + 1e-7, err
     assert err["fp16x2"] <= 3.0 * err["fp32"] + 1e-7, err

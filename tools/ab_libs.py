@@ -24,8 +24,8 @@ def t_us(fn, n=400):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 res = []
-for name, mode, q in (("fwd3b", F.MATH_BF16X3, "0"), ("fwd3p", F.MATH_BF16X3_PIPE, "0"), ("fwd3q", F.MATH_BF16X3_PIPE, "1")):
-    F.set_math_mode(mode); os.environ["LSNF_PIPE16"] = q
+for name, mode in (("fwd3b", getattr(F, "MATH_BF16X3_PHASED", F.MATH_BF16X3)), ("fwd3p", F.MATH_BF16X3_PIPE), ("fwd3q", F.MATH_BF16X3)):
+    F.set_math_mode(mode)
     res.append(f"{name} {t_us(lambda: lsnf_amd.forward(plan, z, out=outs)):.2f}")
 F.set_math_mode(F.MATH_BF16X3)
 z1, ld, ll, saved = lsnf_amd.forward(plan, z, save_for_backward=True)[:4] if False else (None, None, None, None)

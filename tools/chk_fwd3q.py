@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""GPU: the 16x16x32 form of the software-pipelined bf16x3 forward (lsnf_fwd3q_kernel, LSNF_PIPE16=1 inside math mode
-BF16X3_PIPE) against the phase-separated kernel (lsnf_fwd3b_kernel), the 32x32x16 pipeline and the fp32-MFMA kernel:
+"""GPU: the 16x16x32 form of the software-pipelined bf16x3 forward (lsnf_fwd3q_kernel, the default of math mode BF16X3) against the phase-separated kernel (lsnf_fwd3b_kernel), the 32x32x16 pipeline and the fp32-MFMA kernel:
 differences, then kernel-only times at the headline size (alternating, two rounds)."""
 import os
 import sys
@@ -14,14 +13,12 @@ F = lsnf_amd.flow
 w = bench.synth_weights(1)
 plan = lsnf_amd.prepare([t.to(dev) for t in w], bench.NZ, bench.WIDTH, bench.DEPTH)
 F.set_small_batch_max(0)
-KERNELS = {"fwd3b (16x16x32, phases)": (F.MATH_BF16X3, "0"), "fwd3p (32x32x16, pipelined)": (F.MATH_BF16X3_PIPE, "0"),
-           "fwd3q (16x16x32, pipelined)": (F.MATH_BF16X3_PIPE, "1"), "fp32 MFMA": (F.MATH_FP32, "0")}
+KERNELS = {"fwd3b (16x16x32, phases)": F.MATH_BF16X3_PHASED, "fwd3p (32x32x16, pipelined)": F.MATH_BF16X3_PIPE,
+           "fwd3q (16x16x32, pipelined)": F.MATH_BF16X3, "fp32 MFMA": F.MATH_FP32}
 
 
 def select(name):
-    mode, q = KERNELS[name]
-    F.set_math_mode(mode)
-    os.environ["LSNF_PIPE16"] = q
+    F.set_math_mode(KERNELS[name])
 
 
 def run(z, name, stats=False):

@@ -14,8 +14,7 @@ lib = lsnf_amd.load_library()
 lib.lsnf_debug_stamps.restype = ctypes.c_void_p
 hip = ctypes.CDLL("libamdhip64.so")
 which = sys.argv[1] if len(sys.argv) > 1 else "p"          # p: lsnf_fwd3p_kernel (32x32x16), q: lsnf_fwd3q_kernel (16x16x32)
-os.environ["LSNF_PIPE16"] = "1" if which == "q" else "0"
-lsnf_amd.flow.set_math_mode(lsnf_amd.flow.MATH_BF16X3_PIPE)
+lsnf_amd.flow.set_math_mode(lsnf_amd.flow.MATH_BF16X3 if which == "q" else lsnf_amd.flow.MATH_BF16X3_PIPE)
 lsnf_amd.flow.set_small_batch_max(0)
 t0 = time.perf_counter(); n = 0
 while time.perf_counter() - t0 < 2.5:
