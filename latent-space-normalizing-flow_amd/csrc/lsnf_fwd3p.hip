@@ -422,17 +422,15 @@ __device__ __forceinline__ f32x16 from_tile16(const Tile16& t) {
     return x;
 }
 // The bias of an output tile (its 2 x 4 values per lane) is the C operand of the FIRST MFMA of each accumulator chain: both
-// sample tiles start from the same registers, nothing is copied (an initialised accumulator pair would cost 8 v_mov per tile)
-struct Bias16 { f32x4v b[2]; };
-__device__ __forceinline__ Bias16 bias16(const float* cst, int g) {
-    Bias16 t;
+// sample tiles start from the same registers, nothing is copied (an initialised accumulator pair would cost 8 v_mov per tile).
+// It is read from the constant block in LDS one step ahead of that MFMA (4 registers in flight instead of 8 per tile up front).
+__device__ __forceinline__ const float* bias_lane_ptr(const float* cb, int g) { return cb + (g & 1) * 16 + 4 * (g >> 1); }
+__device__ __forceinline__ f32x4v bias_quad(const float* lane_ptr, int float_off) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(lane_ptr + float_off);
+    f32x4v r;
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(cst + (g & 1) * 16 + 4 * (2 * ft + (g >> 1)));
-#pragma unroll
-        for (int r = 0; r < 4; ++r) t.b[ft][r] = v[r];
-    }
-    return t;
+    for (int j = 0; j < 4; ++j) r[j] = v[j];
+    return r;
 }
 template <class PH> constexpr bool first_touch(int i) {       // is step i the first one on its (accumulator, ft)?
     for (int j = 0; j < i; ++j)
@@ -480,23 +478,26 @@ __device__ __forceinline__ void pin12() {       // 12 MFMAs, NV VALU spread behi
 }
 // StepDesc here: acc = output tile, s = its 16-feature half ft, tile = input k-tile, frag as above
 template <class PH, class Fill, class Mid>
-__device__ __forceinline__ void run_phase16(Tile16* acc, const Bias16* bias, const SplitTile16* in, const float* lbuf, int lane, Fill&& fill, Mid&& mid) {
+__device__ __forceinline__ void run_phase16(Tile16* acc, const float* bias_ptr /* bias_lane_ptr of the block */, const SplitTile16* in, const float* lbuf, int lane, Fill&& fill, Mid&& mid) {
     const bf16x8* wp = reinterpret_cast<const bf16x8*>(lbuf) + lane;
     __builtin_amdgcn_sched_barrier(0);
     bf16x8 a[3];
 #pragma unroll
     for (int p = 0; p < 3; ++p) a[p] = wp[(PH::at(0).frag + p) * 64];
-    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+    f32x4v bq = bias_quad(bias_ptr, 32 * PH::btile(PH::at(0).acc) + 8 * PH::at(0).s);       // (step 0 is a first touch)
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
     lsnf_static_for<PH::N>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr StepDesc d = PH::at(i);
         if constexpr (i == PH::MID) { mid(); __builtin_amdgcn_sched_barrier(0); }
         bf16x8 na[3];
+        f32x4v nbq = bq;
 #pragma unroll
         for (int p = 0; p < 3; ++p) na[p] = a[p];
         if constexpr (i + 1 < PH::N) {
 #pragma unroll
             for (int p = 0; p < 3; ++p) na[p] = wp[(PH::at(i + 1).frag + p) * 64];
+            if constexpr (first_touch<PH>(i + 1)) nbq = bias_quad(bias_ptr, 32 * PH::btile(PH::at(i + 1).acc) + 8 * PH::at(i + 1).s);
         }
 #ifndef LSNF_ABL_NOFILL
         fill(ic);
@@ -504,19 +505,20 @@ __device__ __forceinline__ void run_phase16(Tile16* acc, const Bias16* bias, con
         const SplitTile16& x = in[d.tile];
         constexpr bool first = first_touch<PH>(i);
 #define LSNF_Q_MMA(WI, XI) \
-        acc[d.acc].q[2 * d.s + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[WI], __builtin_bit_cast(bf16x8, u32x4{x.d[0][XI][0], x.d[0][XI][1], x.d[0][XI][2], x.d[0][XI][3]}), (first && WI == 2 && XI == 0) ? bias[d.acc].b[d.s] : acc[d.acc].q[2 * d.s + 0], 0, 0, 0); \
-        acc[d.acc].q[2 * d.s + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[WI], __builtin_bit_cast(bf16x8, u32x4{x.d[1][XI][0], x.d[1][XI][1], x.d[1][XI][2], x.d[1][XI][3]}), (first && WI == 2 && XI == 0) ? bias[d.acc].b[d.s] : acc[d.acc].q[2 * d.s + 1], 0, 0, 0);
+        acc[d.acc].q[2 * d.s + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[WI], __builtin_bit_cast(bf16x8, u32x4{x.d[0][XI][0], x.d[0][XI][1], x.d[0][XI][2], x.d[0][XI][3]}), (first && WI == 2 && XI == 0) ? bq : acc[d.acc].q[2 * d.s + 0], 0, 0, 0); \
+        acc[d.acc].q[2 * d.s + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[WI], __builtin_bit_cast(bf16x8, u32x4{x.d[1][XI][0], x.d[1][XI][1], x.d[1][XI][2], x.d[1][XI][3]}), (first && WI == 2 && XI == 0) ? bq : acc[d.acc].q[2 * d.s + 1], 0, 0, 0);
 #ifdef LSNF_ABL_NOMFMA
         LSNF_Q_MMA(0, 0)
 #else
         LSNF_F3_TERMS(LSNF_Q_MMA)
 #endif
 #undef LSNF_Q_MMA
-        if constexpr (i + 1 < PH::N) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        if constexpr (i + 1 < PH::N) __builtin_amdgcn_sched_group_barrier(0x100, first_touch<PH>(i + 1) ? 4 : 3, 0);
         pin12<PH::valu(i)>();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int p = 0; p < 3; ++p) a[p] = na[p];
+        bq = nbq;
     });
 }
 
@@ -528,12 +530,14 @@ __device__ __forceinline__ void run_phase16(Tile16* acc, const Bias16* bias, con
 // of x[3] (6-7) and its split (8-11: k-tile 3 starts at step 12) of the previous block
 struct QhS1a {
     static constexpr int N = 16, MID = 8;
+    static constexpr int btile(int acc) { return acc; }
     static constexpr StepDesc at(int i) { return mkstep<4>((i >> 1) & 1, (i >> 1) & 1, i >> 2, i >> 2, i & 1); }
     static constexpr int valu(int i) { return i < 2 ? 22 : (i < 6 ? 28 : (i < 8 ? 16 : (i < 12 ? 22 : 0))); }
 };
 // S1b: v[2], v[3]; split v[0], v[1] (S2's input and the next block's x[0], x[1]) under the last eight steps
 struct QhS1b {
     static constexpr int N = 16, MID = 8;
+    static constexpr int btile(int acc) { return 2 + acc; }
     static constexpr StepDesc at(int i) { return mkstep<4>((i >> 1) & 1, (i >> 1) & 1, i >> 2, i >> 2, i & 1); }
     static constexpr int valu(int i) { return i >= 8 ? 22 : 0; }
 };
@@ -541,6 +545,7 @@ struct QhS1b {
 // steps 4-7), S3 k-major (h1[1] is split under its k-tile-0 steps 8-11; h2's halves complete at steps 12..15)
 struct QhS23 {
     static constexpr int N = 16, MID = 8;
+    static constexpr int btile(int acc) { return 4 + acc; }                 // P1 = 4 (nz in 66..128)
     static constexpr StepDesc at(int i) {
         if (i < 8) { const int tl = i >> 2, kt = (i >> 1) & 1; return mkstep<2>(tl, tl, kt, kt, i & 1); }
         const int j = i - 8, kt = j >> 2, tl = (j >> 1) & 1;
@@ -552,6 +557,7 @@ struct QhS23 {
 // order p0, t0, p1, t1
 struct QhS4 {
     static constexpr int N = 16, MID = 8;
+    static constexpr int btile(int acc) { return 8 + (acc == 0 ? 2 : (acc == 1 ? 0 : (acc == 2 ? 3 : 1))); }    // P1 + P2 + P3 = 8; accumulators p0, t0, p1, t1
     static constexpr int torder(int j) { return j == 0 ? 2 : (j == 1 ? 0 : (j == 2 ? 3 : 1)); }     // p0, t0, p1, t1 (buffer tiles)
     static constexpr StepDesc at(int i) { const int kt = i >> 3, j = (i >> 1) & 3; return mkstep<2>(j, torder(j), kt, kt, i & 1); }
     //   steps 0-3: relu+split h2[1] | 9-12: sigmoid(p0) | 12-13: coupling of x[2] | 14-15: the first half of its split
@@ -596,7 +602,8 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
 
     // Loop-carried state: xs[0..1] = split of the block input's first half (= the previous block's split v1), xs[2] with the
     // quads 0, 1 of x[2] split, v[2] = x[2] (fp32, until its split is complete), v[3] = v2[1] BEFORE its coupling, p1 / t1 =
-    // the previous block's pre-sigmoid / shift for it (block 0: p1 = 80, t1 = 0: sigmoid = 1 exactly, log = 0 -- the identity),
+    // the previous block's pre-sigmoid / shift for it (block 0: p1 = 80, t1 = 0: sigmoid = 1 exactly, log = 0 -- the identity;
+    // a peeled first S1a that splits the input tiles under its MFMAs instead measured no faster: 92.5 vs 91.5 us, and 21 registers more),
     // lsum = the running sum of log2(1 + exp(-p)) over all blocks (scaled once, in the epilogue)
     Tile16 v[NZT];
     SplitTile16 xs[NZT];
@@ -633,7 +640,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
         if (blk == 1) P_STAMP(10, "s_memtime");
         // ---- S1a: v[0,1]  (model.py:187; actnorm :244,268 folded); carries the end of the previous block's coupling (:414-418) ----
         {
-            const Bias16 bv[2] = {bias16(cb + 0, g), bias16(cb + 32, g)};
+            const float* bv = bias_lane_ptr(cb, g);
             if (k0 > 0) sync_issue(k0);
             run_phase16<QhS1a>(v, bv, xs, buf0 + (k0 & 1) * SLOT, lane, [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
@@ -646,7 +653,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
         if (blk == 1) P_STAMP(11, "s_memtime");
         // ---- S1b: v[2,3]; split v[0], v[1]: S2's input AND the next block's x[0], x[1] ----
         {
-            const Bias16 bv[2] = {bias16(cb + 64, g), bias16(cb + 96, g)};
+            const float* bv = bias_lane_ptr(cb, g);
             sync_issue(k0 + 1);
             run_phase16<QhS1b>(v + 2, bv, xs, buf0 + ((k0 + 1) & 1) * SLOT, lane, [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
@@ -655,9 +662,13 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
         }
         if (blk == 1) P_STAMP(12, "s_memtime");
         if (!more) {             // last block: the v1 half is final (model.py:422) -- its stores drain under S2..S4
+            // (row indices and addresses are formed HERE from the lane id, not in the prologue and carried through the stack)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int smp[2] = {wbase + (ln & 15), wbase + 16 + (ln & 15)};
 #pragma unroll
             for (int t = 0; t < HT; ++t) {
-                l16_store_tile<HT>(t, from_tile16(v[t]), a.z_out, sample, live, a.nz, a.half, g, a.vec4);
+                l16_store_tile<HT>(t, from_tile16(v[t]), a.z_out, smp, live, a.nz, a.half, g, a.vec4);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -668,7 +679,8 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
         for (int st = 0; st < 2; ++st) { ell[st] = ell[st] + cb[32 * C::NP + 0]; ell[st] = ell[st] + cb[32 * C::NP + 1]; }
         // ---- S2 + S3: h1 = relu(actnorm(v1 @ W1)), h2 = relu(actnorm(h1 @ W2))  (model.py:326-328,307-308) ----
         {
-            const Bias16 bv[4] = {bias16(cb + 32 * (C::P1 + 0), g), bias16(cb + 32 * (C::P1 + 1), g), bias16(cb + 32 * (C::P1 + 2), g), bias16(cb + 32 * (C::P1 + 3), g)};
+            static_assert(C::P1 == 4 && C::P2 == 2 && C::P3 == 2, "bias tile indices of the phase tables");
+            const float* bv = bias_lane_ptr(cb, g);
             sync_issue(k0 + 2);
             run_phase16<QhS23>(hh, bv, vh, buf0 + ((k0 + 2) & 1) * SLOT, lane, [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
@@ -682,7 +694,8 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
         // ---- S4: p0, t0, p1, t1 = fc_zeros(h2), de-interleaved (model.py:347-349,411-413) + coupling (:414-418) ----
         {
             constexpr int B4 = C::P1 + C::P2 + C::P3;
-            const Bias16 bv[4] = {bias16(cb + 32 * (B4 + HT), g), bias16(cb + 32 * (B4 + 0), g), bias16(cb + 32 * (B4 + HT + 1), g), bias16(cb + 32 * (B4 + 1), g)};
+            static_assert(B4 == 8, "bias tile indices of the phase tables");
+            const float* bv = bias_lane_ptr(cb, g);
             split_q16<true>(hh[2], 3, h2s[0]);       // (the last quad of h2[0]: exposed, S4's first step needs it)
             sync_issue(k0 + 3);
             run_phase16<QhS4>(tp, bv, h2s, buf0 + ((k0 + 3) & 1) * SLOT, lane, [&](auto ic) {
@@ -707,21 +720,23 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
 
     // ---- epilogue: z_out, logdet, ll = -0.5*sum z^2 + log(2pi) + logdet (train.py:317-319) ----
     float ss[2] = {ss01[0], ss01[1]};
+    int ln_e = lane;
+    asm volatile("" : "+v"(ln_e));
+    const int smp_e[2] = {wbase + (ln_e & 15), wbase + 16 + (ln_e & 15)};
 #pragma unroll
     for (int t = HT; t < NZT; ++t) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r) ss[q & 1] += v[t].q[q][r] * v[t].q[q][r];
-        l16_store_tile<HT>(t, from_tile16(v[t]), a.z_out, sample, live, a.nz, a.half, g, a.vec4);
+        l16_store_tile<HT>(t, from_tile16(v[t]), a.z_out, smp_e, live, a.nz, a.half, g, a.vec4);
     }
     float ll[2];
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
         ll[st] = (-0.5f * l16_group_sum(ss[st]) + 1.8378770664093453f) + ell[st];
         if (live[st] && g == 0) {
-            int smp = sample[st];
-            asm volatile("" : "+v"(smp));
+            const int smp = smp_e[st];
             a.logdet_out[smp] = ell[st];
             if (a.ll_out) a.ll_out[smp] = ll[st];
         }
