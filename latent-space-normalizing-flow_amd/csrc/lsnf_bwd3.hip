@@ -271,11 +271,25 @@ hipError_t launch_bwd3(const Bwd3Args& a, hipStream_t stream) {
 }
 }  // namespace
 
-// host-side dispatcher (called from lsnf_api.hip); needs the activation stash; hipErrorInvalidValue = not covered
-hipError_t lsnf_launch_backward3_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
-                                   const float* act_saved, const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
-                                   float* g_z_in, int vec4, hipStream_t stream, const LsnfLangevinArgs* lv,
-                                   float* dump, float* gl_total) {
+// host-side dispatcher (called from lsnf_api.hip); needs the activation stash; hipErrorInvalidValue = not covered.
+// The f_width-128 instantiation lives in a second translation unit (lsnf_bwd3w.hip = this file with LSNF_BWD3_WIDE_TU) that is
+// compiled WITHOUT packed fp32 math: measured at B = 65 536 (tools/ab_secondary.py, three builds alternating in one job) the
+// (2,4) kernel is 2 % faster that way (186 vs 190 us), the (2,2) kernel 16 % slower (125.5 vs 108.1 us) -- v_pk_add_f32 /
+// v_pk_mul_f32 wait for the MFMA pipe (tools/micro/shadow.hip) but halve the instruction count of the split, and which
+// effect wins depends on the kernel's phase structure.
+#ifdef LSNF_BWD3_WIDE_TU
+#define LSNF_BWD3_ENTRY lsnf_launch_backward3_z_wide
+#else
+#define LSNF_BWD3_ENTRY lsnf_launch_backward3_z
+hipError_t lsnf_launch_backward3_z_wide(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
+                                        const float* act_saved, const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
+                                        float* g_z_in, int vec4, hipStream_t stream, const LsnfLangevinArgs* lv,
+                                        float* dump, float* gl_total);
+#endif
+hipError_t LSNF_BWD3_ENTRY(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
+                           const float* act_saved, const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
+                           float* g_z_in, int vec4, hipStream_t stream, const LsnfLangevinArgs* lv,
+                           float* dump, float* gl_total) {
     if (!act_saved) return hipErrorInvalidValue;
     Bwd3Args a;
     a.dump = dump; a.gl_total = gl_total; a.width = g.width;
@@ -286,8 +300,13 @@ hipError_t lsnf_launch_backward3_z(const LsnfGeo& g, const float* plan, int B, c
     if (lv) { a.z_cur = lv->z_cur; a.grad_g = lv->grad_g; a.noise = lv->noise; a.z_new = lv->z_new; a.gf_norm = lv->gf_norm;
               a.gg_norm = lv->gg_norm; a.step = lv->step; a.rng = lv->rng; }
     a.ll_scale = ll_scale; a.ll_mode = ll_mode; a.B = B; a.nz = g.nz; a.half = g.half; a.depth = g.depth; a.vec4 = vec4;
+#ifdef LSNF_BWD3_WIDE_TU
+    if (g.HT == 2 && g.WT == 4) return launch_bwd3<Bwd3Cfg<2, 4>>(a, stream);
+#else
     if (g.HT == 1 && g.WT == 1) return launch_bwd3<Bwd3Cfg<1, 1>>(a, stream);
     if (g.HT == 2 && g.WT == 2) return launch_bwd3<Bwd3Cfg<2, 2>>(a, stream);
-    if (g.HT == 2 && g.WT == 4) return launch_bwd3<Bwd3Cfg<2, 4>>(a, stream);
+    if (g.HT == 2 && g.WT == 4)
+        return lsnf_launch_backward3_z_wide(g, plan, B, z_out, z_saved, act_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, vec4, stream, lv, dump, gl_total);
+#endif
     return hipErrorInvalidValue;
 }
