@@ -46,20 +46,27 @@ __device__ __forceinline__ f16x2 pk_f16(float a, float b) {
     const f32x2v v = {a, b};
     return __builtin_convertvector(v, f16x2);                                     // round to nearest even
 }
-// LDS-DMA of KB KiB (1 KiB per wave-instruction), as lsnf_issue_panel
+// LDS-DMA of KB KiB (1 KiB per wave-instruction), as lsnf_issue_panel -- but in the instruction's SGPR-base form
+// (global_load_lds_dwordx4 voffset, s[base:base+1]): the wave-uniform address arithmetic stays on the scalar unit and the
+// per-lane part is ONE loop-invariant register (lane * 16).  Through __builtin_amdgcn_global_load_lds hipcc forms a 64-bit
+// per-lane address with a v_lshl_add_u64 per piece (the builtin's selection has no saddr pattern here), i.e. VALU work at every
+// phase boundary -- exposed in the phase-separated kernels, competing for the issue port in the pipelined one.  The hardware
+// counts these loads in vmcnt like any other; every consumer waits with an explicit s_waitcnt vmcnt(0) (lsnf_panel_barrier).
 template <int KB, int NW>
 __device__ __forceinline__ void issue_kib(const float* __restrict__ gsrc, float* lbuf, int wave, int lane) {
     constexpr int PER_WAVE = (KB + NW - 1) / NW;
-    // wave-uniform base + 32-bit per-lane byte offset: the address arithmetic stays on the scalar unit / in the
-    // instruction's offset field instead of two 64-bit VALU adds per piece (VALU time is not hidden under MFMA here)
     const char* base = reinterpret_cast<const char*>(gsrc);
+    const unsigned lds0 = (unsigned)(size_t)((LSNF_AS3 char*)lbuf);                       // LDS byte address of the buffer
     const unsigned lane_off = (unsigned)lane * 16u;
 #pragma unroll
     for (int s = 0; s < PER_WAVE; ++s) {
         const int seg = s * NW + wave;
         if (KB % NW == 0 || seg < KB) {      // wave-uniform
-            __builtin_amdgcn_global_load_lds((const LSNF_AS1 void*)(base + (size_t)seg * 1024u + lane_off),
-                                             (LSNF_AS3 void*)(lbuf + seg * 256), 16, 0, 0);
+            const char* sb = base + (size_t)seg * 1024u;
+            const unsigned m0v = lds0 + (unsigned)seg * 1024u;
+            unsigned keep_m0;        // (m0 is reserved to the compiler: saved and restored around the instruction that needs it)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep_m0) : "v"(lane_off), "s"(sb), "s"(m0v) : "memory");
         }
     }
 }
