@@ -9,12 +9,8 @@ plan = lsnf_amd.prepare([t.to(dev) for t in bench.synth_weights(1)], bench.NZ, b
 lsnf_amd.flow.set_small_batch_max(0)
 
 
-def t_us(z, mode, old):
+def t_us(z, mode):
     lsnf_amd.flow.set_math_mode(mode)
-    if old:
-        os.environ["LSNF_NO_FWD3P"] = "1"
-    else:
-        os.environ.pop("LSNF_NO_FWD3P", None)
     outs = (torch.empty_like(z), torch.empty(z.shape[0], device=dev), torch.empty(z.shape[0], device=dev))
     for _ in range(1500):
         lsnf_amd.forward(plan, z, out=outs)
@@ -30,9 +26,9 @@ def t_us(z, mode, old):
 
 zr = torch.randn(65536, bench.NZ, generator=torch.Generator().manual_seed(1234)).to(dev)
 zz = torch.zeros_like(zr)
-for name, mode, old in (("lsnf_fwd3p_kernel (32x32x16, pipelined)", lsnf_amd.flow.MATH_BF16X3, False),
-                        ("lsnf_fwd3b_kernel (16x16x32)", lsnf_amd.flow.MATH_BF16X3, True),
-                        ("lsnf_fwd2h_kernel (fp16x2)", lsnf_amd.flow.MATH_FP16X2, True),
-                        ("lsnf_fwd_kernel (fp32 MFMA)", lsnf_amd.flow.MATH_FP32, True)):
-    a, b = t_us(zr, mode, old), t_us(zz, mode, old)
+F = lsnf_amd.flow
+for name, mode in (("lsnf_fwd3q_kernel (16x16x32, pipelined)", F.MATH_BF16X3), ("lsnf_fwd3p_kernel (32x32x16, pipelined)", F.MATH_BF16X3_PIPE),
+                   ("lsnf_fwd3b_kernel (16x16x32, phases)", F.MATH_BF16X3_PHASED), ("lsnf_fwd3_kernel (32x32x16, phases)", F.MATH_BF16X3_32),
+                   ("lsnf_fwd2h_kernel (fp16x2)", F.MATH_FP16X2), ("lsnf_fwd_kernel (fp32 MFMA)", F.MATH_FP32)):
+    a, b = t_us(zr, mode), t_us(zz, mode)
     print(f"{name:44s} random z {a:7.2f} us   zero z {b:7.2f} us   ratio {a / b:.3f}", flush=True)
