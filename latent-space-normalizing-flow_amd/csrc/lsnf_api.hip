@@ -248,7 +248,15 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
     hipError_t e;
     const int math = math_mode();
     const bool split = math == LSNF_MATH_BF16X3 || math == LSNF_MATH_BF16X3_32 || math == LSNF_MATH_BF16X3_PIPE || math == LSNF_MATH_BF16X3_PHASED;
-    if (B <= small_batch_max()) {
+    // With in-kernel batch sums every workgroup ends in two fp64 atomics and a ticket on the SAME addresses (~40 ns each,
+    // serialised at the memory side): the 16-row workgroups of the latency kernels pay 20 us of it at 8 192 rows and 40 us at
+    // 16 384 (tools/shard_times.py: 91.5 vs 53.6 us on the throughput kernel at 16 384 rows, 51 vs 51 at 8 192, 28 vs 50 at
+    // 4 096) -- such calls cross over at 8 192 rows.  (Only the AUTO threshold moves: an explicit setting is obeyed; calls that
+    // write a stash keep the common threshold, so that the family that wrote it is the family that reads it.)
+    int small_max = small_batch_max();
+    if (stats != nullptr && z_saved == nullptr && act_saved == nullptr && small_batch_setting() == LSNF_SMALL_BATCH_AUTO && small_max > 8192)
+        small_max = 8192;
+    if (B <= small_max) {
         e = hipErrorInvalidValue;
         if (l16_math())                           // latency forward on the bf16 pipe: 16-sample workgroups (lsnf_small3_fwd.hip)
             e = lsnf_launch_small3_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,

@@ -433,9 +433,14 @@ hipError_t lsnf_launch_backward_params(const LsnfGeo& g, const float* plan, cons
     t.z_in = z_in; t.z_out = z_out; t.z_saved = z_saved; t.dump = dump; t.fold = fold;
     t.B = B; t.nz = g.nz; t.half = g.half; t.width = g.width; t.depth = g.depth;
     t.chunk = B >= 16384 ? 512 : 128;                // samples per workgroup (multiple of 16; 512: 3 200 workgroups at B = 65 536 -- measured 620 us for the whole call against 672 at 1 024 and 760 at 2 048)
-    { const char* e = getenv("LSNF_TN_ABL"); t.abl = e ? atoi(e) : 0; const char* c = getenv("LSNF_TN_CHUNK"); if (c) t.chunk = atoi(c); }
+    // experiment knobs of tools/tn_probe.py (read once per process): ablation switches, samples per workgroup, plain kernel
+    static const int knob_abl = [] { const char* e = getenv("LSNF_TN_ABL"); return e ? atoi(e) : 0; }();
+    static const int knob_chunk = [] { const char* e = getenv("LSNF_TN_CHUNK"); return e ? atoi(e) : 0; }();
+    static const bool knob_plain = getenv("LSNF_TN_PLAIN") != nullptr;
+    t.abl = knob_abl;
+    if (knob_chunk > 0) t.chunk = knob_chunk;
     const unsigned chunks = (unsigned)((B + t.chunk - 1) / t.chunk);
-    if (B >= 4096 && !getenv("LSNF_TN_PLAIN")) {
+    if (B >= 4096 && !knob_plain) {
         // every row the tasks read starts 16-byte aligned iff nz, width and half are multiples of 4 (z tensors: the caller's
         // alignment is folded into vec4; the dump rows start at 16-byte aligned offsets of the 16-byte aligned workspace)
         const bool a4 = vec4 == 4 && g.nz % 4 == 0 && g.width % 4 == 0 && g.half % 4 == 0;
