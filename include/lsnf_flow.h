@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LSNF_ABI_VERSION 4
+#define LSNF_ABI_VERSION 5
 
 #define LSNF_OK 0
 #define LSNF_E_ARG (-1)       /* bad argument (NULL pointer, size out of range, misaligned) */
@@ -69,7 +69,9 @@ const char* lsnf_last_error(void);
  *                               LSNF_MATH_FP16X2) -- the initial state unless the LSNF_SMALL_MAX environment variable is set;
  *                               returns the previous setting
  *   -1                        : query only: returns the threshold in force (a row count)
- * "previous setting" is a row count or LSNF_SMALL_BATCH_AUTO, so `prev = set(x); ...; set(prev)` restores exactly. */
+ * "previous setting" is a row count or LSNF_SMALL_BATCH_AUTO, so `prev = set(x); ...; set(prev)` restores exactly.
+ * Under LSNF_SMALL_BATCH_AUTO one kind of call has its own crossover: lsnf_forward WITHOUT z_saved / act_saved in
+ * LSNF_MATH_BF16X3 at nz in 66..128, f_width <= 64 switches to the (software-pipelined) throughput kernel above 8192 rows. */
 #define LSNF_SMALL_BATCH_AUTO (-2)
 int lsnf_set_small_batch_max(int rows);
 
@@ -154,11 +156,13 @@ int lsnf_prepare(const float* const* params_host, int nz, int width, int depth, 
  *             activations h1, h2 of every block into it, which lets lsnf_backward_params run FROM THE STASH instead of
  *             recomputing the coupling MLP.  Whole stack only, with act_saved and z_saved; needs a bf16x3-family math
  *             mode (lsnf_params_fast_path() == 1, LSNF_E_ARG otherwise).
- *   stats     NULL, or 8 doubles (device, 8-byte aligned) that the caller zero-initialises ONCE:
+ *   stats     NULL, or LSNF_STATS_DOUBLES doubles (device, 8-byte aligned) that the caller zero-initialises ONCE:
  *             after the launch stats[4] = sum_b ll_b (train.py:320), stats[5] = sum_b logdet_b,
- *             stats[6] = B.  Summed inside the kernel (fp64 atomics, one pair per workgroup; the last
- *             workgroup publishes and re-arms stats[0..2], which are internal).  One stats buffer
- *             must not be shared by launches on different streams.                            */
+ *             stats[6] = B.  Summed inside the kernel (fp64 atomics, one pair per workgroup, two-level: the
+ *             workgroups add into 64 sub-accumulators stats[8..], the last arrival of each forwards its total,
+ *             the last of those publishes; everything but stats[4..6] is internal and re-armed by the launch).
+ *             One stats buffer must not be shared by launches on different streams.            */
+#define LSNF_STATS_DOUBLES 264
 int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling,
                  int first_block, int n_blocks, int B,
                  const float* z_in, const float* objective,

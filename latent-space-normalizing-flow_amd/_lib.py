@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LSNF_LIB_PATH") or os.path.join(_HERE, "liblsnf_flow.so")
 
 LSNF_PARAMS_PER_BLOCK = 12
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 class LsnfRng(ctypes.Structure):
     """include/lsnf_flow.h `LsnfRng`: in-kernel Philox noise of lsnf_langevin_step."""

@@ -248,13 +248,14 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
     hipError_t e;
     const int math = math_mode();
     const bool split = math == LSNF_MATH_BF16X3 || math == LSNF_MATH_BF16X3_32 || math == LSNF_MATH_BF16X3_PIPE || math == LSNF_MATH_BF16X3_PHASED;
-    // With in-kernel batch sums every workgroup ends in two fp64 atomics and a ticket on the SAME addresses (~40 ns each,
-    // serialised at the memory side): the 16-row workgroups of the latency kernels pay 20 us of it at 8 192 rows and 40 us at
-    // 16 384 (tools/shard_times.py: 91.5 vs 53.6 us on the throughput kernel at 16 384 rows, 51 vs 51 at 8 192, 28 vs 50 at
-    // 4 096) -- such calls cross over at 8 192 rows.  (Only the AUTO threshold moves: an explicit setting is obeyed; calls that
-    // write a stash keep the common threshold, so that the family that wrote it is the family that reads it.)
+    // Calls without a stash that the software-pipelined forward covers cross over at 8 192 rows, not at the common threshold:
+    // the latency kernel's time is a staircase of 16.5 us per 4 096 rows (one round of 16-row workgroups), lsnf_fwd3q_kernel
+    // takes 48 us up to 16 384 rows (tools/shard_times.py: 34 vs 47.5 us at 8 192 rows, 50 vs 48 at 10 240, 66 vs 49 at 16 384).
+    // Only the AUTO threshold moves (an explicit setting is obeyed); calls that write a stash keep the common threshold, so
+    // that the family that wrote it is the family that reads it (tools/crossover2.py: 75 vs 69 us at 16 384 rows for those).
     int small_max = small_batch_max();
-    if (stats != nullptr && z_saved == nullptr && act_saved == nullptr && small_batch_setting() == LSNF_SMALL_BATCH_AUTO && small_max > 8192)
+    if (z_saved == nullptr && act_saved == nullptr && small_batch_setting() == LSNF_SMALL_BATCH_AUTO && small_max > 8192 &&
+        math == LSNF_MATH_BF16X3 && g.HT == 2 && g.WT == 2)
         small_max = 8192;
     if (B <= small_max) {
         e = hipErrorInvalidValue;

@@ -57,22 +57,42 @@ struct LsnfStackCfg {
 // flush this workgroup's freshly written z_out lines: +2..6 us per workgroup).  The workgroup that draws the last
 // ticket reads the totals with atomic read-modify-writes (a plain or sc1 load could be served by this XCD's L2, which
 // is not coherent with the other XCDs), publishes them and re-arms the accumulators for the next launch.
-__device__ __forceinline__ void lsnf_publish_stats(double* stats, double sum_ll, double sum_logdet, int rows) {
-    const double r0 = atomicAdd(&stats[0], sum_ll);
-    const double r1 = atomicAdd(&stats[1], sum_logdet);
+// Two levels: atomics on ONE address serialise at the memory side (~40 ns each: 40 us for the 1 024 workgroups of a
+// 16 384-row latency launch, tools/shard_times.py), so grids of more than LSNF_STATS_SLOTS workgroups add into
+// LSNF_STATS_SLOTS sub-accumulators (stats[8 + 4 s ..]: sum ll, sum logdet, ticket), and the last arrival of each
+// sub-accumulator forwards its total to the launch-wide pair.
+#define LSNF_STATS_SLOTS 64
+__device__ __forceinline__ bool lsnf_stats_add(double* acc /* [0] ll, [1] logdet, [2] ticket */, double sum_ll, double sum_logdet,
+                                               unsigned long long arrivals, double* tot_ll, double* tot_logdet) {
+    const double r0 = atomicAdd(&acc[0], sum_ll);
+    const double r1 = atomicAdd(&acc[1], sum_logdet);
     unsigned long long inc = 1ull;
     asm volatile("" : "+v"(inc) : "v"(r0), "v"(r1));
-    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(&stats[2]);
+    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(&acc[2]);
     const unsigned long long t = atomicAdd(ticket, inc);
-    if (t == (unsigned long long)gridDim.x - 1) {
-        const double fl = atomicAdd(&stats[0], 0.0);
-        const double fd = atomicAdd(&stats[1], 0.0);
-        stats[4] = fl; stats[5] = fd; stats[6] = (double)rows;
-        // re-arm, fire and forget (a non-finite sum cannot be subtracted away: NaN - NaN stays NaN for every later launch)
-        if (fl - fl == 0.0) atomicAdd(&stats[0], -fl); else atomicExch(reinterpret_cast<unsigned long long*>(&stats[0]), 0ull);
-        if (fd - fd == 0.0) atomicAdd(&stats[1], -fd); else atomicExch(reinterpret_cast<unsigned long long*>(&stats[1]), 0ull);
-        atomicExch(ticket, 0ull);
+    if (t != arrivals - 1) return false;
+    const double fl = atomicAdd(&acc[0], 0.0);
+    const double fd = atomicAdd(&acc[1], 0.0);
+    *tot_ll = fl; *tot_logdet = fd;
+    // re-arm, fire and forget (a non-finite sum cannot be subtracted away: NaN - NaN stays NaN for every later launch)
+    if (fl - fl == 0.0) atomicAdd(&acc[0], -fl); else atomicExch(reinterpret_cast<unsigned long long*>(&acc[0]), 0ull);
+    if (fd - fd == 0.0) atomicAdd(&acc[1], -fd); else atomicExch(reinterpret_cast<unsigned long long*>(&acc[1]), 0ull);
+    atomicExch(ticket, 0ull);
+    return true;
+}
+__device__ __forceinline__ void lsnf_publish_stats(double* stats, double sum_ll, double sum_logdet, int rows) {
+    const unsigned grid = gridDim.x, wg = blockIdx.x;
+    double fl, fd;
+    if (grid > LSNF_STATS_SLOTS) {
+        const unsigned s = wg % LSNF_STATS_SLOTS;
+        const unsigned long long n_s = (grid - s + LSNF_STATS_SLOTS - 1) / LSNF_STATS_SLOTS;       // workgroups of this slot
+        if (!lsnf_stats_add(stats + 8 + 4 * s, sum_ll, sum_logdet, n_s, &fl, &fd)) return;
+        sum_ll = fl; sum_logdet = fd;
+        if (!lsnf_stats_add(stats, sum_ll, sum_logdet, LSNF_STATS_SLOTS, &fl, &fd)) return;
+    } else {
+        if (!lsnf_stats_add(stats, sum_ll, sum_logdet, grid, &fl, &fd)) return;
     }
+    stats[4] = fl; stats[5] = fd; stats[6] = (double)rows;
 }
 
 // feature offset inside a 32-tile of accumulator register r on lane-half h

@@ -201,9 +201,12 @@ def new_params_workspace(plan: "FlowPlan", B: int, device) -> torch.Tensor:
     return torch.empty(max(n, 4), dtype=torch.float32, device=device)
 
 
+STATS_DOUBLES = 264          # include/lsnf_flow.h LSNF_STATS_DOUBLES
+
+
 def new_stats(device) -> torch.Tensor:
-    """Zero-initialised 8-double accumulator for `forward(..., stats=)` (one per stream)."""
-    return torch.zeros(8, dtype=torch.float64, device=device)
+    """Zero-initialised accumulator (LSNF_STATS_DOUBLES = 264 doubles) for `forward(..., stats=)` (one per stream)."""
+    return torch.zeros(STATS_DOUBLES, dtype=torch.float64, device=device)
 
 
 def reverse(plan: FlowPlan, z: torch.Tensor, objective: Optional[torch.Tensor] = None):

@@ -15,6 +15,8 @@ from typing import Callable, Iterable, List, Optional, Sequence, Tuple
 import torch
 import torch.distributed as dist
 
+STATS_DOUBLES = 264          # include/lsnf_flow.h LSNF_STATS_DOUBLES (= flow.STATS_DOUBLES; no import of the HIP binding here)
+
 
 def init_from_env(device: Optional[torch.device] = None, backend: Optional[str] = None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run sets them).
@@ -90,7 +92,7 @@ class PipelinedStatsReducer:
 
     The all-reduce of [sum ll, sum logdet, rows] is ~20 us of pure latency on 8 GPUs; nothing in the Langevin loop
     consumes the reduced value before the next flow evaluation starts (it is a logged diagnostic, train.py:320,332).
-    So the sums of `bucket` consecutive evaluations are gathered in one bank (row j = the 8-double stats buffer of
+    So the sums of `bucket` consecutive evaluations are gathered in one bank (row j = the stats buffer of
     evaluation j, filled by the forward kernel itself) and travel in ONE asynchronous all-reduce per bank, on the
     communication stream, WHILE the next bank is being filled: every evaluation's sums are still reduced, but a
     collective kernel competes with the forward kernels for a CU (they fill the chip exactly: one workgroup per CU) only
@@ -109,7 +111,7 @@ class PipelinedStatsReducer:
     def __init__(self, device, group=None, make_buffer=None, bucket: int = 1):
         if bucket < 1:
             raise ValueError("bucket must be >= 1")
-        mk = make_buffer or (lambda n: torch.zeros(n, 8, dtype=torch.float64, device=device))
+        mk = make_buffer or (lambda n: torch.zeros(n, STATS_DOUBLES, dtype=torch.float64, device=device))
         self.bucket = bucket
         self.banks = [mk(bucket), mk(bucket)]
         self.work = [None, None]
@@ -131,7 +133,7 @@ class PipelinedStatsReducer:
         if self.fill == 0:
             return
         if self._multi():
-            # the whole bank in one message: the kernel-internal slots 0..3 are zero at rest and stay zero; rows of a
+            # the whole bank in one message (2 KiB per row): the kernel-internal slots are zero at rest and stay zero; rows of a
             # partly filled bank (finish() only) that were not written this time carry stale values nobody reads
             self.work[self.bank] = dist.all_reduce(self.banks[self.bank], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.bank ^= 1

@@ -69,7 +69,7 @@ int main(void) {
     double* dstats;
     CHECK(hipMalloc((void**)&dz1, sizeof(float) * B * NZ)); CHECK(hipMalloc((void**)&dback, sizeof(float) * B * NZ));
     CHECK(hipMalloc((void**)&dld, sizeof(float) * B)); CHECK(hipMalloc((void**)&dll, sizeof(float) * B)); CHECK(hipMalloc((void**)&dobj, sizeof(float) * B));
-    CHECK(hipMalloc((void**)&dstats, 8 * sizeof(double))); CHECK(hipMemset(dstats, 0, 8 * sizeof(double)));
+    CHECK(hipMalloc((void**)&dstats, LSNF_STATS_DOUBLES * sizeof(double))); CHECK(hipMemset(dstats, 0, LSNF_STATS_DOUBLES * sizeof(double)));
 
     int fails = 0;
     for (int family = 0; family < 2; ++family) {                 /* latency kernels, then throughput kernels */

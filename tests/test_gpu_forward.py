@@ -300,9 +300,10 @@ def test_errors_are_loud(lsnf, gpu_device):
     assert z1.shape == (0, 8) and ll.shape == (0,)
 
 
-@pytest.mark.parametrize("B", [1, 100, 129, 5000])
+@pytest.mark.parametrize("B", [1, 100, 129, 5000, 20000])
 def test_in_kernel_batch_sums(lsnf, kernels, gpu_device, B):
-    """stats: sum ll / sum logdet / rows accumulated by the kernel itself, re-armed for every launch."""
+    """stats: sum ll / sum logdet / rows accumulated by the kernel itself, re-armed for every launch (grids of more than 64
+    workgroups go through the 64 sub-accumulators of the buffer: they too must be back at zero)."""
     p = O.init_params(128, 64, 5, seed=2)
     plan = lsnf.prepare(lsnf.params_from_state_dict(p, 5, gpu_device), 128, 64, 5)
     stats = lsnf.flow.new_stats(gpu_device)
@@ -313,6 +314,7 @@ def test_in_kernel_batch_sums(lsnf, kernels, gpu_device, B):
         assert abs(s[4].item() - ll.double().sum().item()) <= 1e-9 * abs(ll.double().sum().item()) + 1e-9
         assert abs(s[5].item() - ld.double().sum().item()) <= 1e-9 * abs(ld.double().sum().item()) + 1e-9
         assert s[6].item() == B and s[0].item() == 0.0 and s[1].item() == 0.0 and s[2].item() == 0.0
+        assert s.numel() == lsnf.flow.STATS_DOUBLES and s[8:].view(torch.int64).abs().max().item() == 0
     lsnf.forward(plan, torch.zeros(0, 128, device=gpu_device), stats=stats)
     assert stats.cpu()[4:7].tolist() == [0.0, 0.0, 0.0]
 

@@ -91,7 +91,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/lsnf_flow.h but not exported"
     assert sorted(lsnf_amd.exported_symbols()) == declared      # the ctypes table covers the whole header
-    assert lib.lsnf_abi_version() == 4
+    assert lib.lsnf_abi_version() == 5
 
 
 def test_geometry_queries_need_no_gpu():
