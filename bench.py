@@ -52,7 +52,7 @@ PEAK_HBM_GBS = 8000.0
 # executed MFMA flops per algorithmic flop, pipe peak, kernel of the mode (B = 65 536 instantiation)
 MODES = {
     "bf16x3": dict(exec_per_alg=6, peak=PEAK_BF16_MFMA_TFLOPS, pipe="bf16 MFMA", dtype="bf16x3",
-                   kernel="lsnf_fwd3q_kernel<2, 8>"),
+                   kernel="lsnf_fwd3q_kernel<2, 8, 2>"),
     "fp32": dict(exec_per_alg=1, peak=PEAK_FP32_MFMA_TFLOPS, pipe="fp32 MFMA", dtype="f32",
                  kernel="lsnf_fwd_kernel<FwdCfg<2,2>, 8>"),
     "fp16x2": dict(exec_per_alg=3, peak=PEAK_BF16_MFMA_TFLOPS, pipe="fp16 MFMA", dtype="fp16x2",

@@ -71,7 +71,7 @@ const char* lsnf_last_error(void);
  *   -1                        : query only: returns the threshold in force (a row count)
  * "previous setting" is a row count or LSNF_SMALL_BATCH_AUTO, so `prev = set(x); ...; set(prev)` restores exactly.
  * Under LSNF_SMALL_BATCH_AUTO one kind of call has its own crossover: lsnf_forward WITHOUT z_saved / act_saved in
- * LSNF_MATH_BF16X3 at nz in 66..128, f_width <= 64 switches to the (software-pipelined) throughput kernel above 8192 rows. */
+ * LSNF_MATH_BF16X3 at nz in 66..128, f_width <= 64 switches to the (software-pipelined) throughput kernel above 4096 rows. */
 #define LSNF_SMALL_BATCH_AUTO (-2)
 int lsnf_set_small_batch_max(int rows);
 

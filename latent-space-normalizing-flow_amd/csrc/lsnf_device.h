@@ -83,7 +83,11 @@ __device__ __forceinline__ bool lsnf_stats_add(double* acc /* [0] ll, [1] logdet
 __device__ __forceinline__ void lsnf_publish_stats(double* stats, double sum_ll, double sum_logdet, int rows) {
     const unsigned grid = gridDim.x, wg = blockIdx.x;
     double fl, fd;
+#ifdef LSNF_STATS_SINGLE     // timing diagnostic: one level for every grid
+    if (false) {
+#else
     if (grid > LSNF_STATS_SLOTS) {
+#endif
         const unsigned s = wg % LSNF_STATS_SLOTS;
         const unsigned long long n_s = (grid - s + LSNF_STATS_SLOTS - 1) / LSNF_STATS_SLOTS;       // workgroups of this slot
         if (!lsnf_stats_add(stats + 8 + 4 * s, sum_ll, sum_logdet, n_s, &fl, &fd)) return;

@@ -405,21 +405,56 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3p_kernel(const Fwd3pA
 struct Tile16 { f32x4v q[4]; };                  // q[2*ft + st]: features 16*ft + 4*g + r of sample 16*st + n
 struct SplitTile16 { unsigned d[2][3][4]; };     // [st][part][dword 2*ft + j] = the B operands of one k-tile
 
-__device__ __forceinline__ Tile16 to_tile16(const f32x16& x) {
-    Tile16 t;
+// ST = sample tiles per wave: 2 (32 rows per wave) or 1 (16 rows per wave: the same kernel for launches that would otherwise
+// leave SIMDs idle -- twice the workgroups per row; the quads q = 2*ft + 1 of a Tile16 and d[1] of a SplitTile16 are unused)
+template <int HT, int ST>
+__device__ __forceinline__ Tile16 load_tile16(int t, const float* __restrict__ z, const int* rows, int nz, int half, int g, int vw) {
+    Tile16 x;
+    const int hh = t / HT, tt = t % HT;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) t.q[q][r] = x[4 * q + r];
-    return t;
-}
-__device__ __forceinline__ f32x16 from_tile16(const Tile16& t) {
-    f32x16 x;
+        for (int st = 0; st < ST; ++st) {
+            const int f0 = 32 * tt + l16_feat0(ft, g), col0 = hh * half + f0, q = 2 * ft + st;
+            const float* zr = z + (long)rows[st] * (long)nz;
+            if (vw == 4) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (f0 < half) v = *reinterpret_cast<const f32x4*>(zr + col0);
+                x.q[q][0] = v[0]; x.q[q][1] = v[1]; x.q[q][2] = v[2]; x.q[q][3] = v[3];
+            } else if (vw == 2) {
+                f32x2 v0 = {0.f, 0.f}, v1 = {0.f, 0.f};
+                if (f0 < half) v0 = *reinterpret_cast<const f32x2*>(zr + col0);
+                if (f0 + 2 < half) v1 = *reinterpret_cast<const f32x2*>(zr + col0 + 2);
+                x.q[q][0] = v0[0]; x.q[q][1] = v0[1]; x.q[q][2] = v1[0]; x.q[q][3] = v1[1];
+            } else {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x[4 * q + r] = t.q[q][r];
+                for (int j = 0; j < 4; ++j) x.q[q][j] = (f0 + j < half) ? zr[col0 + j] : 0.0f;
+            }
+        }
     return x;
+}
+template <int HT, int ST>
+__device__ __forceinline__ void store_tile16(int t, const Tile16& x, float* __restrict__ z, const int* rows, const bool* live,
+                                             int nz, int half, int g, int vw) {
+    const int hh = t / HT, tt = t % HT;
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int st = 0; st < ST; ++st) {
+            if (!live[st]) continue;
+            const int f0 = 32 * tt + l16_feat0(ft, g), col0 = hh * half + f0, q = 2 * ft + st;
+            float* zr = z + (long)rows[st] * (long)nz;
+            if (vw == 4) {
+                if (f0 < half) { f32x4 v = {x.q[q][0], x.q[q][1], x.q[q][2], x.q[q][3]}; *reinterpret_cast<f32x4*>(zr + col0) = v; }
+            } else if (vw == 2) {
+                if (f0 < half) { f32x2 v = {x.q[q][0], x.q[q][1]}; *reinterpret_cast<f32x2*>(zr + col0) = v; }
+                if (f0 + 2 < half) { f32x2 v = {x.q[q][2], x.q[q][3]}; *reinterpret_cast<f32x2*>(zr + col0 + 2) = v; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (f0 + j < half) zr[col0 + j] = x.q[q][j];
+            }
+        }
 }
 // The bias of an output tile (its 2 x 4 values per lane) is the C operand of the FIRST MFMA of each accumulator chain: both
 // sample tiles start from the same registers, nothing is copied (an initialised accumulator pair would cost 8 v_mov per tile).
@@ -437,13 +472,20 @@ template <class PH> constexpr bool first_touch(int i) {       // is step i the f
         if (PH::at(j).acc == PH::at(i).acc && PH::at(j).s == PH::at(i).s) return false;
     return true;
 }
-// quad q = 2*ft + st of a tile (optionally through ReLU) -> dwords 2*ft, 2*ft + 1 of sample tile st: 18 (22) VALU
-template <bool RELU>
+// One unit of vector work, indexed q = 0..3 in the phase tables.  ST = 2: quad q = 2*ft + st of a tile (4 values per lane).
+// ST = 1: the tile has the quads 2*ft only, and unit q = 2*ft + j is the element PAIR j of quad 2*ft -- half the work per
+// unit, under half the MFMAs per step, with the same readiness (a unit depends on the 16-feature half ft = q >> 1 only).
+template <int ST> __device__ __forceinline__ constexpr int unit_quad(int q) { return ST == 2 ? q : (q & ~1); }
+template <int ST> __device__ __forceinline__ constexpr int unit_pair0(int q) { return ST == 2 ? 0 : (q & 1); }
+template <int ST> __device__ __forceinline__ constexpr int unit_st(int q) { return ST == 2 ? (q & 1) : 0; }
+// unit q (optionally through ReLU) -> its dwords of the B operands: 22 (26) VALU per quad
+template <bool RELU, int ST>
 __device__ __forceinline__ void split_q16(const Tile16& x, int q, SplitTile16& out) {
-    const int ft = q >> 1, st = q & 1;
+    const int ft = q >> 1, st = unit_st<ST>(q), qr = unit_quad<ST>(q);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        float a = x.q[q][2 * j], b = x.q[q][2 * j + 1];
+    for (int jj = 0; jj < ST; ++jj) {
+        const int j = unit_pair0<ST>(q) + jj;
+        float a = x.q[qr][2 * j], b = x.q[qr][2 * j + 1];
         if (RELU) { a = fmaxf(a, 0.0f); b = fmaxf(b, 0.0f); }
         const unsigned p1 = pk_bf16(a, b);
         a -= __builtin_bit_cast(float, p1 << 16); b -= __builtin_bit_cast(float, p1 & 0xffff0000u);
@@ -454,30 +496,34 @@ __device__ __forceinline__ void split_q16(const Tile16& x, int q, SplitTile16& o
         keep(out.d[st][0][d], out.d[st][1][d], out.d[st][2][d]);
     }
 }
+template <int ST>
 __device__ __forceinline__ void sigmoid_q16(Tile16& p, int q, float* lsum /*[2]: per sample tile*/) {
+    const int st = unit_st<ST>(q), qr = unit_quad<ST>(q), r0 = 2 * unit_pair0<ST>(q);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = r0; r < r0 + 2 * ST; ++r) {
         float sig, l2;
-        lsnf_sigmoid_log2(p.q[q][r], sig, l2);
-        p.q[q][r] = sig; lsum[q & 1] += l2;
+        lsnf_sigmoid_log2(p.q[qr][r], sig, l2);
+        p.q[qr][r] = sig; lsum[st] += l2;
     }
-    keep(p.q[q][0], p.q[q][1], p.q[q][2], p.q[q][3], lsum[q & 1]);
+    keep(p.q[qr][r0], p.q[qr][r0 + 1], p.q[qr][r0 + 2 * ST - 2], p.q[qr][r0 + 2 * ST - 1], lsum[st]);
 }
+template <int ST>
 __device__ __forceinline__ void couple_q16(Tile16& v, const Tile16& t, const Tile16& sig, int q) {
+    const int qr = unit_quad<ST>(q), r0 = 2 * unit_pair0<ST>(q);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v.q[q][r] = (v.q[q][r] + t.q[q][r]) * sig.q[q][r];
+    for (int r = r0; r < r0 + 2 * ST; ++r) v.q[qr][r] = (v.q[qr][r] + t.q[qr][r]) * sig.q[qr][r];
 }
 
-template <int NV>
-__device__ __forceinline__ void pin12() {       // 12 MFMAs, NV VALU spread behind them (the first NV % 12 slots carry one more)
-    lsnf_static_for<12>([&](auto mc) {
-        constexpr int m = decltype(mc)::value, V = NV / 12 + (m < NV % 12 ? 1 : 0);
+template <int NM, int NV>
+__device__ __forceinline__ void pin_mfma() {       // NM MFMAs, NV VALU spread behind them (the first NV % NM slots carry one more)
+    lsnf_static_for<NM>([&](auto mc) {
+        constexpr int m = decltype(mc)::value, V = NV / NM + (m < NV % NM ? 1 : 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         if constexpr (V > 0) __builtin_amdgcn_sched_group_barrier(0x402, V, 0);
     });
 }
 // StepDesc here: acc = output tile, s = its 16-feature half ft, tile = input k-tile, frag as above
-template <class PH, class Fill, class Mid>
+template <class PH, int ST, class Fill, class Mid>
 __device__ __forceinline__ void run_phase16(Tile16* acc, const float* bias_ptr /* bias_lane_ptr of the block */, const SplitTile16* in, const float* lbuf, int lane, Fill&& fill, Mid&& mid) {
     const bf16x8* wp = reinterpret_cast<const bf16x8*>(lbuf) + lane;
     __builtin_amdgcn_sched_barrier(0);
@@ -506,7 +552,7 @@ __device__ __forceinline__ void run_phase16(Tile16* acc, const float* bias_ptr /
         constexpr bool first = first_touch<PH>(i);
 #define LSNF_Q_MMA(WI, XI) \
         acc[d.acc].q[2 * d.s + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[WI], __builtin_bit_cast(bf16x8, u32x4{x.d[0][XI][0], x.d[0][XI][1], x.d[0][XI][2], x.d[0][XI][3]}), (first && WI == 2 && XI == 0) ? bq : acc[d.acc].q[2 * d.s + 0], 0, 0, 0); \
-        acc[d.acc].q[2 * d.s + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[WI], __builtin_bit_cast(bf16x8, u32x4{x.d[1][XI][0], x.d[1][XI][1], x.d[1][XI][2], x.d[1][XI][3]}), (first && WI == 2 && XI == 0) ? bq : acc[d.acc].q[2 * d.s + 1], 0, 0, 0);
+        if constexpr (ST == 2) acc[d.acc].q[2 * d.s + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[WI], __builtin_bit_cast(bf16x8, u32x4{x.d[1][XI][0], x.d[1][XI][1], x.d[1][XI][2], x.d[1][XI][3]}), (first && WI == 2 && XI == 0) ? bq : acc[d.acc].q[2 * d.s + 1], 0, 0, 0);
 #ifdef LSNF_ABL_NOMFMA
         LSNF_Q_MMA(0, 0)
 #else
@@ -514,7 +560,7 @@ __device__ __forceinline__ void run_phase16(Tile16* acc, const float* bias_ptr /
 #endif
 #undef LSNF_Q_MMA
         if constexpr (i + 1 < PH::N) __builtin_amdgcn_sched_group_barrier(0x100, first_touch<PH>(i + 1) ? 4 : 3, 0);
-        pin12<PH::valu(i)>();
+        pin_mfma<6 * ST, (PH::valu(i) * ST) / 2>();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int p = 0; p < 3; ++p) a[p] = na[p];
@@ -564,7 +610,7 @@ struct QhS4 {
     static constexpr int valu(int i) { return i < 4 ? 26 : (i < 9 ? 0 : (i < 12 ? 28 : (i == 12 ? 36 : (i == 13 ? 24 : 22)))); }
 };
 
-template <int WT, int NWAVES>
+template <int WT, int NWAVES, int ST>
 __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pArgs a) {
     using C = Fwd3pCfg<WT>;
     static_assert(WT == 2, "lsnf_fwd3q_kernel: f_width <= 64 instantiation");
@@ -595,10 +641,10 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
     issue_kib<48, NWAVES>(phase_src(0), buf0, wave, lane);
     for (int i = tid; i < a.n_blocks * C::CONST_FLOATS; i += THREADS) cst[i] = a.consts[i];
 
-    const int wbase = (blockIdx.x * NWAVES + wave) * 32;
-    int sample[2], rows[2]; bool live[2];
+    const int wbase = (blockIdx.x * NWAVES + wave) * (16 * ST);
+    int sample[2] = {0, 0}, rows[2] = {0, 0}; bool live[2] = {false, false};
 #pragma unroll
-    for (int st = 0; st < 2; ++st) { sample[st] = wbase + 16 * st + n; live[st] = sample[st] < a.B; rows[st] = live[st] ? sample[st] : a.B - 1; }
+    for (int st = 0; st < ST; ++st) { sample[st] = wbase + 16 * st + n; live[st] = sample[st] < a.B; rows[st] = live[st] ? sample[st] : a.B - 1; }
 
     // Loop-carried state: xs[0..1] = split of the block input's first half (= the previous block's split v1), xs[2] with the
     // quads 0, 1 of x[2] split, v[2] = x[2] (fp32, until its split is complete), v[3] = v2[1] BEFORE its coupling, p1 / t1 =
@@ -610,13 +656,13 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
     Tile16 p1, t1;
     float lsum[2] = {0.0f, 0.0f};
     {
-        const Tile16 x0 = to_tile16(l16_load_tile<HT>(0, a.z_in, rows, a.nz, a.half, g, a.vec4));
-        const Tile16 x1 = to_tile16(l16_load_tile<HT>(1, a.z_in, rows, a.nz, a.half, g, a.vec4));
-        v[2] = to_tile16(l16_load_tile<HT>(2, a.z_in, rows, a.nz, a.half, g, a.vec4));
-        v[3] = to_tile16(l16_load_tile<HT>(3, a.z_in, rows, a.nz, a.half, g, a.vec4));
+        const Tile16 x0 = load_tile16<HT, ST>(0, a.z_in, rows, a.nz, a.half, g, a.vec4);
+        const Tile16 x1 = load_tile16<HT, ST>(1, a.z_in, rows, a.nz, a.half, g, a.vec4);
+        v[2] = load_tile16<HT, ST>(2, a.z_in, rows, a.nz, a.half, g, a.vec4);
+        v[3] = load_tile16<HT, ST>(3, a.z_in, rows, a.nz, a.half, g, a.vec4);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { split_q16<false>(x0, q, xs[0]); split_q16<false>(x1, q, xs[1]); }     // (not hidden: once per launch)
-        split_q16<false>(v[2], 0, xs[2]); split_q16<false>(v[2], 1, xs[2]);
+        for (int q = 0; q < 4; ++q) { split_q16<false, ST>(x0, q, xs[0]); split_q16<false, ST>(x1, q, xs[1]); }     // (not hidden: once per launch)
+        split_q16<false, ST>(v[2], 0, xs[2]); split_q16<false, ST>(v[2], 1, xs[2]);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -624,7 +670,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
     }
     float ell[2];
 #pragma unroll
-    for (int st = 0; st < 2; ++st) ell[st] = a.objective ? a.objective[rows[st]] : 0.0f;
+    for (int st = 0; st < 2; ++st) ell[st] = (st < ST && a.objective) ? a.objective[rows[st]] : 0.0f;
     float ss01[2] = {0.0f, 0.0f};
     sync_issue(0);
     P_STAMP(1, "s_memtime");
@@ -642,12 +688,12 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
         {
             const float* bv = bias_lane_ptr(cb, g);
             if (k0 > 0) sync_issue(k0);
-            run_phase16<QhS1a>(v, bv, xs, buf0 + (k0 & 1) * SLOT, lane, [&](auto ic) {
+            run_phase16<QhS1a, ST>(v, bv, xs, buf0 + (k0 & 1) * SLOT, lane, [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                if constexpr (i < 2) split_q16<false>(v[2], 2 + i, xs[2]);                 // x[2]: k-tile 2 starts at step 8
-                else if constexpr (i < 6) sigmoid_q16(p1, i - 2, lsum);
-                else if constexpr (i < 8) { couple_q16(v[3], t1, p1, 2 * (i - 6)); couple_q16(v[3], t1, p1, 2 * (i - 6) + 1); }
-                else if constexpr (i < 12) split_q16<false>(v[3], i - 8, xs[3]);           // x[3]: k-tile 3 starts at step 12
+                if constexpr (i < 2) split_q16<false, ST>(v[2], 2 + i, xs[2]);                 // x[2]: k-tile 2 starts at step 8
+                else if constexpr (i < 6) sigmoid_q16<ST>(p1, i - 2, lsum);
+                else if constexpr (i < 8) { couple_q16<ST>(v[3], t1, p1, 2 * (i - 6)); couple_q16<ST>(v[3], t1, p1, 2 * (i - 6) + 1); }
+                else if constexpr (i < 12) split_q16<false, ST>(v[3], i - 8, xs[3]);           // x[3]: k-tile 3 starts at step 12
             }, [] {});
         }
         if (blk == 1) P_STAMP(11, "s_memtime");
@@ -655,9 +701,9 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
         {
             const float* bv = bias_lane_ptr(cb, g);
             sync_issue(k0 + 1);
-            run_phase16<QhS1b>(v + 2, bv, xs, buf0 + ((k0 + 1) & 1) * SLOT, lane, [&](auto ic) {
+            run_phase16<QhS1b, ST>(v + 2, bv, xs, buf0 + ((k0 + 1) & 1) * SLOT, lane, [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                if constexpr (i >= 8) split_q16<false>(v[(i - 8) >> 2], i & 3, vh[(i - 8) >> 2]);    // (xs[0], xs[1] are dead by now: k order)
+                if constexpr (i >= 8) split_q16<false, ST>(v[(i - 8) >> 2], i & 3, vh[(i - 8) >> 2]);    // (xs[0], xs[1] are dead by now: k order)
             }, [] {});
         }
         if (blk == 1) P_STAMP(12, "s_memtime");
@@ -668,11 +714,13 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
             const int smp[2] = {wbase + (ln & 15), wbase + 16 + (ln & 15)};
 #pragma unroll
             for (int t = 0; t < HT; ++t) {
-                l16_store_tile<HT>(t, from_tile16(v[t]), a.z_out, smp, live, a.nz, a.half, g, a.vec4);
+                store_tile16<HT, ST>(t, v[t], a.z_out, smp, live, a.nz, a.half, g, a.vec4);
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ss01[q & 1] += v[t].q[q][r] * v[t].q[q][r];
+                    for (int st = 0; st < ST; ++st)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ss01[st] += v[t].q[2 * ft + st][r] * v[t].q[2 * ft + st][r];
             }
         }
 #pragma unroll
@@ -682,11 +730,11 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
             static_assert(C::P1 == 4 && C::P2 == 2 && C::P3 == 2, "bias tile indices of the phase tables");
             const float* bv = bias_lane_ptr(cb, g);
             sync_issue(k0 + 2);
-            run_phase16<QhS23>(hh, bv, vh, buf0 + ((k0 + 2) & 1) * SLOT, lane, [&](auto ic) {
+            run_phase16<QhS23, ST>(hh, bv, vh, buf0 + ((k0 + 2) & 1) * SLOT, lane, [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                if constexpr (i >= 4 && i < 8) split_q16<true>(hh[0], i - 4, vh[2]);      // h1[0] under h1[1]'s steps
-                if constexpr (i >= 8 && i < 12) split_q16<true>(hh[1], i - 8, vh[3]);     // h1[1] under S3's k-tile 0
-                if constexpr (i >= 13) split_q16<true>(hh[2], i - 13, h2s[0]);             // h2[0]: its halves complete after steps 12, 13
+                if constexpr (i >= 4 && i < 8) split_q16<true, ST>(hh[0], i - 4, vh[2]);      // h1[0] under h1[1]'s steps
+                if constexpr (i >= 8 && i < 12) split_q16<true, ST>(hh[1], i - 8, vh[3]);     // h1[1] under S3's k-tile 0
+                if constexpr (i >= 13) split_q16<true, ST>(hh[2], i - 13, h2s[0]);             // h2[0]: its halves complete after steps 12, 13
             }, [] {});
         }
         if (blk == 1) P_STAMP(13, "s_memtime");
@@ -696,16 +744,16 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
             constexpr int B4 = C::P1 + C::P2 + C::P3;
             static_assert(B4 == 8, "bias tile indices of the phase tables");
             const float* bv = bias_lane_ptr(cb, g);
-            split_q16<true>(hh[2], 3, h2s[0]);       // (the last quad of h2[0]: exposed, S4's first step needs it)
+            split_q16<true, ST>(hh[2], 3, h2s[0]);       // (the last quad of h2[0]: exposed, S4's first step needs it)
             sync_issue(k0 + 3);
-            run_phase16<QhS4>(tp, bv, h2s, buf0 + ((k0 + 3) & 1) * SLOT, lane, [&](auto ic) {
+            run_phase16<QhS4, ST>(tp, bv, h2s, buf0 + ((k0 + 3) & 1) * SLOT, lane, [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                if constexpr (i < 4) split_q16<true>(hh[3], i, h2s[1]);                    // h2[1] under k-tile 0
+                if constexpr (i < 4) split_q16<true, ST>(hh[3], i, h2s[1]);                    // h2[1] under k-tile 0
                 // k-tile 1: p0's halves are complete after steps 8, 9; t0's after 10, 11; p1's after 12, 13; t1's after 14, 15
-                if constexpr (i >= 9 && i < 13) sigmoid_q16(tp[0], i - 9, lsum);
-                if constexpr (i == 12) couple_q16(v[2], tp[1], tp[0], 0);
-                if constexpr (i == 13) { couple_q16(v[2], tp[1], tp[0], 1); couple_q16(v[2], tp[1], tp[0], 2); couple_q16(v[2], tp[1], tp[0], 3); }
-                if constexpr (i >= 14) split_q16<false>(v[2], i - 14, xs[2]);
+                if constexpr (i >= 9 && i < 13) sigmoid_q16<ST>(tp[0], i - 9, lsum);
+                if constexpr (i == 12) couple_q16<ST>(v[2], tp[1], tp[0], 0);
+                if constexpr (i == 13) { couple_q16<ST>(v[2], tp[1], tp[0], 1); couple_q16<ST>(v[2], tp[1], tp[0], 2); couple_q16<ST>(v[2], tp[1], tp[0], 3); }
+                if constexpr (i >= 14) split_q16<false, ST>(v[2], i - 14, xs[2]);
             }, [] {});
             p1 = tp[2]; t1 = tp[3];              // (the rest of the coupling rides under the next block's S1a)
         }
@@ -714,9 +762,9 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
     P_STAMP(40, "s_memtime");
     // the last block's x[3] (no S1a follows)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { sigmoid_q16(p1, q, lsum); couple_q16(v[3], t1, p1, q); }
+    for (int q = 0; q < 4; ++q) { sigmoid_q16<ST>(p1, q, lsum); couple_q16<ST>(v[3], t1, p1, q); }
 #pragma unroll
-    for (int st = 0; st < 2; ++st) ell[st] = ell[st] + -0.6931471805599453f * l16_group_sum(lsum[st]);
+    for (int st = 0; st < ST; ++st) ell[st] = ell[st] + -0.6931471805599453f * l16_group_sum(lsum[st]);
 
     // ---- epilogue: z_out, logdet, ll = -0.5*sum z^2 + log(2pi) + logdet (train.py:317-319) ----
     float ss[2] = {ss01[0], ss01[1]};
@@ -726,14 +774,16 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
 #pragma unroll
     for (int t = HT; t < NZT; ++t) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ss[q & 1] += v[t].q[q][r] * v[t].q[q][r];
-        l16_store_tile<HT>(t, from_tile16(v[t]), a.z_out, smp_e, live, a.nz, a.half, g, a.vec4);
+            for (int st = 0; st < ST; ++st)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ss[st] += v[t].q[2 * ft + st][r] * v[t].q[2 * ft + st][r];
+        store_tile16<HT, ST>(t, v[t], a.z_out, smp_e, live, a.nz, a.half, g, a.vec4);
     }
-    float ll[2];
+    float ll[2] = {0.0f, 0.0f};
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
+    for (int st = 0; st < ST; ++st) {
         ll[st] = (-0.5f * l16_group_sum(ss[st]) + 1.8378770664093453f) + ell[st];
         if (live[st] && g == 0) {
             const int smp = smp_e[st];
@@ -744,7 +794,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
     if (a.stats) {
         double dl = 0.0, dd = 0.0;
 #pragma unroll
-        for (int st = 0; st < 2; ++st)
+        for (int st = 0; st < ST; ++st)
             if (live[st] && g == 0) { dl += (double)ll[st]; dd += (double)ell[st]; }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) { dl += __shfl_xor(dl, o, 64); dd += __shfl_xor(dd, o, 64); }
@@ -762,15 +812,15 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
     P_STAMP(51, "s_memrealtime");
 }
 
-template <int WT, int NWAVES>
+template <int WT, int NWAVES, int ST>
 hipError_t launch_fwd3q_w(const Fwd3pArgs& a, hipStream_t stream) {
     using C = Fwd3pCfg<WT>;
     const size_t lds = ((size_t)a.n_blocks * C::CONST_FLOATS + 2 * (size_t)C::SLOT3) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = lsnf_fwd3q_kernel<WT, NWAVES>;
+    auto kern = lsnf_fwd3q_kernel<WT, NWAVES, ST>;
     static unsigned long long lds_ok = 0;
     if (hipError_t e = lsnf_allow_big_lds((const void*)kern, &lds_ok); e != hipSuccess) return e;
-    const unsigned grid = (unsigned)((a.B + 32 * NWAVES - 1) / (32 * NWAVES));
+    const unsigned grid = (unsigned)((a.B + 16 * ST * NWAVES - 1) / (16 * ST * NWAVES));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NWAVES), lds, stream, a);
     return hipGetLastError();
 }
@@ -826,5 +876,12 @@ hipError_t lsnf_launch_forward3q(const LsnfGeo& g, const float* plan, int first_
       if (!g_lsnf_stamps) { if (hipMalloc(&g_lsnf_stamps, sizeof(unsigned long long) * 64 * 4 * 4096) != hipSuccess) g_lsnf_stamps = nullptr; }
       a.stamps = g_lsnf_stamps; }
 #endif
-    return B > 128 * 256 ? launch_fwd3q_w<2, 8>(a, stream) : launch_fwd3q_w<2, 4>(a, stream);
+    // workgroup shape by batch size (one workgroup per CU; 256 CUs): 256 rows (8 waves x 32) above 32 768 rows; below, 16 rows
+    // per wave so that the grid still covers the chip -- 8 waves x 16 rows down to 16 384 rows, 4 waves x 16 rows below
+    static const char* shape = getenv("LSNF_FWD3Q_SHAPE");     // experiment knob (tools/shard_times.py): "82", "42", "81", "41"
+    const int sh = shape ? atoi(shape) : (B > 128 * 256 ? 82 : (B > 64 * 256 ? 81 : 41));
+    if (sh == 82) return launch_fwd3q_w<2, 8, 2>(a, stream);
+    if (sh == 42) return launch_fwd3q_w<2, 4, 2>(a, stream);
+    if (sh == 81) return launch_fwd3q_w<2, 8, 1>(a, stream);
+    return launch_fwd3q_w<2, 4, 1>(a, stream);
 }

@@ -22,7 +22,7 @@ shutil.copy(os.path.join(R, "secondary.json"), os.path.join(P, f"{tag}_secondary
 open(os.path.join(P, f"{tag}_run_secondary.json"), "w").write(last(os.path.join(R, "run_secondary.json")))
 rows = list(csv.DictReader(open(os.path.join(R, "prof", "bench_kernel_trace.csv"))))
 out = {}
-for key, name in (("lsnf_fwd3q", "lsnf_fwd3q_kernel<2, 8>"), ("lsnf_fwd3b", "lsnf_fwd3b_kernel<Fwd3Cfg<2,2>, 8>"), ("lsnf_fwd2h", "lsnf_fwd2h_kernel<Fwd3Cfg<2,2>, 8>"),
+for key, name in (("lsnf_fwd3q", "lsnf_fwd3q_kernel<2, 8, 2>"), ("lsnf_fwd3b", "lsnf_fwd3b_kernel<Fwd3Cfg<2,2>, 8>"), ("lsnf_fwd2h", "lsnf_fwd2h_kernel<Fwd3Cfg<2,2>, 8>"),
                   ("lsnf_fwd_kernel", "lsnf_fwd_kernel<FwdCfg<2,2>, 8>")):
     rr = sorted((r for r in rows if key in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
     d_all = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rr]

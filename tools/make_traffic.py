@@ -10,7 +10,7 @@ def mean(counter, p):
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and KEY in r["Kernel_Name"]]
     return sum(v) / len(v)
 fetch_kb, write_kb = mean("FETCH_SIZE", "p3"), mean("WRITE_SIZE", "p4")
-out = {"kernel": {"bf16x3": "lsnf_fwd3q_kernel<2, 8>", "fp16x2": "lsnf_fwd2h_kernel<Fwd3Cfg<2,2>, 8>"}.get(math, "lsnf_fwd_kernel<FwdCfg<2,2>, 8 waves>"), "workload": "nz=128 w=64 depth=5 B=65536",
+out = {"kernel": {"bf16x3": "lsnf_fwd3q_kernel<2, 8, 2>", "fp16x2": "lsnf_fwd2h_kernel<Fwd3Cfg<2,2>, 8>"}.get(math, "lsnf_fwd_kernel<FwdCfg<2,2>, 8 waves>"), "workload": "nz=128 w=64 depth=5 B=65536",
        "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
        "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024,
        "algorithmic_bytes_per_launch": 1032 * 65536,
