@@ -300,6 +300,33 @@ def test_errors_are_loud(lsnf, gpu_device):
     assert z1.shape == (0, 8) and ll.shape == (0,)
 
 
+@pytest.mark.parametrize("B", [4096, 4097, 9000, 16384, 16385, 24000, 32768, 32769, 40000])
+def test_midsize_batches_default_dispatch(lsnf, gpu_device, B):
+    """Untouched thresholds and default arithmetic: the stash-less forward crosses from the latency kernel to the pipelined
+    throughput kernel at 4 096 rows and changes its workgroup shape at 16 384 and 32 768 rows (4 x 16, 8 x 16, 8 x 32 rows per
+    workgroup) -- every shape against the oracle on a strided sample of rows, with and without in-kernel sums, and
+    row-independent (a prefix launched alone on another shape gives the same rows to fp32 rounding)."""
+    nz, width, depth = 128, 64, 5
+    p = O.init_params(nz, width, depth, seed=5, fcz_std=0.05)
+    plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
+    assert lsnf.flow.set_small_batch_max(-1) == 16384 and lsnf.flow.set_math_mode(-1) == lsnf.flow.MATH_BF16X3
+    z = torch.randn(B, nz, generator=torch.Generator().manual_seed(B))
+    zd = z.to(gpu_device)
+    stats = lsnf.flow.new_stats(gpu_device)
+    z1, ld, ll, _ = lsnf.forward(plan, zd)
+    z1s, lds, lls, _ = lsnf.forward(plan, zd, stats=stats)
+    assert torch.equal(z1, z1s) and torch.equal(ll, lls) and torch.equal(ld, lds)
+    s = stats.cpu()
+    assert abs(s[4].item() - ll.double().sum().item()) <= 1e-9 * abs(ll.double().sum().item()) and s[6].item() == B
+    idx = torch.cat([torch.arange(0, B, 101), torch.tensor([B - 1])])
+    z1r, ldr, llr = O.flow_log_prob(p, z[idx])
+    assert ((ll.cpu()[idx] - llr).abs() / llr.abs().clamp_min(1.0)).max().item() <= LL_REL
+    assert (z1.cpu()[idx] - z1r).abs().max().item() <= Z_ABS
+    half = B // 2
+    z1h, ldh, llh, _ = lsnf.forward(plan, zd[:half].contiguous())
+    assert (z1[:half] - z1h).abs().max().item() <= 2e-5 and ((ll[:half] - llh).abs() / llh.abs().clamp_min(1.0)).max().item() <= 2e-6
+
+
 @pytest.mark.parametrize("B", [1, 100, 129, 5000, 20000])
 def test_in_kernel_batch_sums(lsnf, kernels, gpu_device, B):
     """stats: sum ll / sum logdet / rows accumulated by the kernel itself, re-armed for every launch (grids of more than 64
