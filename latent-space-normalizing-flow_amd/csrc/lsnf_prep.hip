@@ -21,37 +21,42 @@ enum { P_AB = 0, P_ALOGS, P_W, P_W1, P_B1, P_LOGS1, P_W2, P_B2, P_LOGS2, P_W3, P
 __host__ __device__ static inline size_t scratch_block_doubles(int nz) { return (size_t)nz * nz + 8; }
 
 // ---------------------------------------------------------------------------------------------
-// (1) Gauss-Jordan with partial pivoting, float64, one workgroup (16 x 16 threads) per block.
-// The matrix lives in REGISTERS: thread (ry, cx) owns the 8 x 8 elements A[ry + 16*rr][cx + 16*jj].
+// (1) Gauss-Jordan with partial pivoting, float64, one workgroup (T x T threads) per block.
+// The matrix lives in REGISTERS: thread (ry, cx) owns the E x E elements A[ry + T*rr][cx + T*jj], E = 128 / T.
 // Per column only the pivot column, the pivot row and the displaced row travel through LDS
 // (ping-pong buffers -> 2 barriers per column); every wave finds the pivot redundantly by shuffles.
+// T = 32 (1 024 threads, 4 x 4 elements each): a column step is a chain of dependent instructions (publish, barrier, pivot
+// search, fp64 reciprocal, barrier, eliminate), so four waves per SIMD with a quarter of the per-thread work each run it
+// ~3x faster than T = 16 with one wave per SIMD (tools/prep_loop.py under rocprofv3: 241 us -> see profiles/).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lsnf_gj_kernel(LsnfParamPtrs pp, int nz, double* scratch) {
+template <int T>
+__global__ __launch_bounds__(T * T) void lsnf_gj_kernel(LsnfParamPtrs pp, int nz, double* scratch) {
+    constexpr int E = 128 / T;
     __shared__ double colbuf[2][128], rowp[2][128], rowc[2][128];
     __shared__ double pivs[128];
-    __shared__ int perm[128], cinv[128];
+    __shared__ int perm[128], cinv[128], cmap[128];
     const int n = nz;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int ry = tid >> 4, cx = tid & 15;
+    const int ry = tid / T, cx = tid % T;
     const int blk = blockIdx.x;
     const float* W = pp.p[blk * 12 + P_W];
-    double a[8][8];
+    double a[E][E];
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr)
+    for (int rr = 0; rr < E; ++rr)
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const int r = ry + 16 * rr, j = cx + 16 * jj;
+        for (int jj = 0; jj < E; ++jj) {
+            const int r = ry + T * rr, j = cx + T * jj;
             a[rr][jj] = (r < n && j < n) ? (double)W[r * n + j] : ((r == j) ? 1.0 : 0.0);   // identity padding
         }
     for (int c = 0; c < n; ++c) {
-        const int pb = c & 1, cjj = c >> 4, ccx = c & 15;
+        const int pb = c & 1, cjj = c / T, ccx = c % T;
         // (A) owners of column c publish it
         if (cx == ccx) {
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj)
+            for (int jj = 0; jj < E; ++jj)
                 if (jj == cjj) {
 #pragma unroll
-                    for (int rr = 0; rr < 8; ++rr) colbuf[pb][ry + 16 * rr] = a[rr][jj];
+                    for (int rr = 0; rr < E; ++rr) colbuf[pb][ry + T * rr] = a[rr][jj];
                 }
         }
         __syncthreads();
@@ -72,22 +77,22 @@ __global__ __launch_bounds__(256) void lsnf_gj_kernel(LsnfParamPtrs pp, int nz, 
         const int p = 127 - (int)(key & 127u);
         const double pv = colbuf[pb][p];
         const double old_cc = colbuf[pb][c];          // A[c][c] before the exchange (multiplier of row p afterwards)
-        const int prr = p >> 4, pry = p & 15, crr = c >> 4, cry = c & 15;
+        const int prr = p / T, pry = p % T, crr = c / T, cry = c % T;
         // (C) owners of rows p and c publish them
         if (ry == pry) {
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr)
+            for (int rr = 0; rr < E; ++rr)
                 if (rr == prr) {
 #pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) rowp[pb][cx + 16 * jj] = a[rr][jj];
+                    for (int jj = 0; jj < E; ++jj) rowp[pb][cx + T * jj] = a[rr][jj];
                 }
         }
         if (ry == cry) {
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr)
+            for (int rr = 0; rr < E; ++rr)
                 if (rr == crr) {
 #pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) rowc[pb][cx + 16 * jj] = a[rr][jj];
+                    for (int jj = 0; jj < E; ++jj) rowc[pb][cx + T * jj] = a[rr][jj];
                 }
         }
         if (tid == 0) perm[c] = p;
@@ -97,47 +102,46 @@ __global__ __launch_bounds__(256) void lsnf_gj_kernel(LsnfParamPtrs pp, int nz, 
         //     overwritten by their owners -- keeps the 64-FMA body free of per-element selects.
         const double ipv = 1.0 / pv;
         if (tid == 0) pivs[c] = pv;
-        double pr[8], f[8];
+        double pr[E], f[E];
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) { const int j = cx + 16 * jj; pr[jj] = ((j == c) ? 1.0 : rowp[pb][j]) * ipv; }
+        for (int jj = 0; jj < E; ++jj) { const int j = cx + T * jj; pr[jj] = ((j == c) ? 1.0 : rowp[pb][j]) * ipv; }
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) f[rr] = colbuf[pb][ry + 16 * rr];
+        for (int rr = 0; rr < E; ++rr) f[rr] = colbuf[pb][ry + T * rr];
         if (cx == ccx) {
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj)
+            for (int jj = 0; jj < E; ++jj)
                 if (jj == cjj) {
 #pragma unroll
-                    for (int rr = 0; rr < 8; ++rr) a[rr][jj] = 0.0;
+                    for (int rr = 0; rr < E; ++rr) a[rr][jj] = 0.0;
                 }
         }
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr)
+        for (int rr = 0; rr < E; ++rr)
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) a[rr][jj] = fma(-f[rr], pr[jj], a[rr][jj]);
+            for (int jj = 0; jj < E; ++jj) a[rr][jj] = fma(-f[rr], pr[jj], a[rr][jj]);
         if (ry == pry && p != c) {          // row p now holds the old row c, eliminated with multiplier old A[c][c]
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr)
+            for (int rr = 0; rr < E; ++rr)
                 if (rr == prr) {
 #pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) {
-                        const int j = cx + 16 * jj;
+                    for (int jj = 0; jj < E; ++jj) {
+                        const int j = cx + T * jj;
                         a[rr][jj] = fma(-old_cc, pr[jj], (j == c) ? 0.0 : rowc[pb][j]);
                     }
                 }
         }
         if (ry == cry) {                    // row c becomes the scaled pivot row
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr)
+            for (int rr = 0; rr < E; ++rr)
                 if (rr == crr) {
 #pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) a[rr][jj] = pr[jj];
+                    for (int jj = 0; jj < E; ++jj) a[rr][jj] = pr[jj];
                 }
         }
     }
     // undo the row interchanges as column interchanges: out[:, cinv[j]] = A[:, j]
     __syncthreads();
     if (tid == 0) {
-        int cmap[128];
         for (int j = 0; j < 128; ++j) cmap[j] = j;
         for (int c = n - 1; c >= 0; --c) { const int p = perm[c]; if (p != c) { const int t = cmap[c]; cmap[c] = cmap[p]; cmap[p] = t; } }
         for (int j = 0; j < n; ++j) cinv[cmap[j]] = j;   // position j of the result holds work-column cmap[j]
@@ -145,20 +149,27 @@ __global__ __launch_bounds__(256) void lsnf_gj_kernel(LsnfParamPtrs pp, int nz, 
     __syncthreads();
     double* out = scratch + (size_t)blk * scratch_block_doubles(nz);
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr)
+    for (int rr = 0; rr < E; ++rr)
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const int r = ry + 16 * rr, j = cx + 16 * jj;
+        for (int jj = 0; jj < E; ++jj) {
+            const int r = ry + T * rr, j = cx + T * jj;
             if (r < n && j < n) out[r * n + cinv[j]] = a[rr][jj];
         }
-    if (tid == 0) {
+    {   // log|det W| = sum log|pivot| and sum(3 logs): one term per thread, summed by wave 0 and wave 1
         const float* logs = pp.p[blk * 12 + P_ALOGS];
         // reference: torch.sum(logs * 3) in fp32 (model.py:264,273); each term logs*3 is rounded
         // to fp32 first, then summed -- we sum those fp32 terms in double and round once.
-        double s3 = 0.0, logabs = 0.0;
-        for (int k = 0; k < n; ++k) { s3 += (double)(logs[k] * 3.0f); logabs += log(fabs(pivs[k])); }
-        out[(size_t)n * n + 0] = logabs;
-        out[(size_t)n * n + 1] = s3;
+        if (tid < 128) {
+            double la = tid < n ? log(fabs(pivs[tid])) : 0.0, s3 = tid < n ? (double)(logs[tid] * 3.0f) : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { la += __shfl_xor(la, o, 64); s3 += __shfl_xor(s3, o, 64); }
+            if (lane == 0) { colbuf[0][tid >> 6] = la; rowp[0][tid >> 6] = s3; }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            out[(size_t)n * n + 0] = colbuf[0][0] + colbuf[0][1];
+            out[(size_t)n * n + 1] = rowp[0][0] + rowp[0][1];
+        }
     }
 }
 
@@ -461,7 +472,7 @@ hipError_t lsnf_launch_prepare(const LsnfGeo& g, const float* const* params_host
     LsnfParamPtrs pp;
     for (int i = 0; i < g.depth * 12; ++i) pp.p[i] = params_host[i];
     for (int i = g.depth * 12; i < LSNF_MAX_DEPTH * 12; ++i) pp.p[i] = nullptr;
-    hipLaunchKernelGGL(lsnf_gj_kernel, dim3(g.depth), dim3(256), 0, stream, pp, g.nz, (double*)scratch);
+    hipLaunchKernelGGL(lsnf_gj_kernel<32>, dim3(g.depth), dim3(1024), 0, stream, pp, g.nz, (double*)scratch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int per_block = g.fwd_const_floats + g.fwd_block_floats + g.inv_const_floats + g.inv_block_floats +
