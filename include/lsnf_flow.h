@@ -158,9 +158,9 @@ int lsnf_prepare(const float* const* params_host, int nz, int width, int depth, 
  *             mode (lsnf_params_fast_path() == 1, LSNF_E_ARG otherwise).
  *   stats     NULL, or LSNF_STATS_DOUBLES doubles (device, 8-byte aligned) that the caller zero-initialises ONCE:
  *             after the launch stats[4] = sum_b ll_b (train.py:320), stats[5] = sum_b logdet_b,
- *             stats[6] = B.  Summed inside the kernel (fp64 atomics, one pair per workgroup, two-level: the
- *             workgroups add into 64 sub-accumulators stats[8..], the last arrival of each forwards its total,
- *             the last of those publishes; everything but stats[4..6] is internal and re-armed by the launch).
+ *             stats[6] = B.  Summed inside the kernel (fp64 atomics, one pair per workgroup, into 64
+ *             sub-accumulators stats[8..]; tickets find the last workgroup, which reads them all, publishes and
+ *             re-arms them; everything but stats[4..6] is internal and back at zero after the launch).
  *             One stats buffer must not be shared by launches on different streams.            */
 #define LSNF_STATS_DOUBLES 264
 int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling,

@@ -51,52 +51,51 @@ struct LsnfStackCfg {
     static constexpr int SLOT = 2 * MAXKT * LSNF_FRAG_FLOATS;  // LDS floats of one panel PAIR (throughput kernels)
 };
 
-// In-kernel batch sums (stats argument of lsnf_forward): called by ONE lane per workgroup with the workgroup's partial
-// sums.  Returning atomics: their values come back only after the adds have been performed at the memory side, and the
-// ticket increment is made to depend on them -- ordering without an L2 write-back fence (a release fence here would
-// flush this workgroup's freshly written z_out lines: +2..6 us per workgroup).  The workgroup that draws the last
-// ticket reads the totals with atomic read-modify-writes (a plain or sc1 load could be served by this XCD's L2, which
-// is not coherent with the other XCDs), publishes them and re-arms the accumulators for the next launch.
-// Two levels: atomics on ONE address serialise at the memory side (~40 ns each: 40 us for the 1 024 workgroups of a
-// 16 384-row latency launch, tools/shard_times.py), so grids of more than LSNF_STATS_SLOTS workgroups add into
-// LSNF_STATS_SLOTS sub-accumulators (stats[8 + 4 s ..]: sum ll, sum logdet, ticket), and the last arrival of each
-// sub-accumulator forwards its total to the launch-wide pair.
+// In-kernel batch sums (stats argument of lsnf_forward): called by ALL 64 lanes of ONE wave per workgroup, lane 0 holding
+// the workgroup's partial sums.  No fences (a release fence here would flush this workgroup's freshly written z_out lines:
+// +2..6 us per workgroup); ordering comes from RETURNING atomics, whose values come back only after the operation has been
+// performed at the memory side, and from making every later step depend on them:
+//   1. lane 0 adds the partial sums into sub-accumulator s = workgroup % 64 (stats[8 + 4 s ..]: sum ll, sum logdet, ticket);
+//   2. it draws the sub-accumulator's ticket (grids of more than 64 workgroups; otherwise every workgroup has its own slot);
+//   3. the last arrival of a sub-accumulator draws the launch-wide ticket (stats[2]);
+//   4. the last of those reads all 64 sub-accumulators -- one atomic exchange with zero per lane, which re-arms them for the
+//      next launch as well (a plain load could be served by this XCD's L2, which is not coherent with the other XCDs) --
+//      and publishes stats[4..6].
+// Atomics on ONE address serialise at the memory side (~40 ns each: 40 us for the 1 024 workgroups of a 16 384-row latency
+// launch with a single accumulator, tools/shard_times.py); the longest chain here is four dependent round trips.
 #define LSNF_STATS_SLOTS 64
-__device__ __forceinline__ bool lsnf_stats_add(double* acc /* [0] ll, [1] logdet, [2] ticket */, double sum_ll, double sum_logdet,
-                                               unsigned long long arrivals, double* tot_ll, double* tot_logdet) {
-    const double r0 = atomicAdd(&acc[0], sum_ll);
-    const double r1 = atomicAdd(&acc[1], sum_logdet);
-    unsigned long long inc = 1ull;
-    asm volatile("" : "+v"(inc) : "v"(r0), "v"(r1));
-    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(&acc[2]);
-    const unsigned long long t = atomicAdd(ticket, inc);
-    if (t != arrivals - 1) return false;
-    const double fl = atomicAdd(&acc[0], 0.0);
-    const double fd = atomicAdd(&acc[1], 0.0);
-    *tot_ll = fl; *tot_logdet = fd;
-    // re-arm, fire and forget (a non-finite sum cannot be subtracted away: NaN - NaN stays NaN for every later launch)
-    if (fl - fl == 0.0) atomicAdd(&acc[0], -fl); else atomicExch(reinterpret_cast<unsigned long long*>(&acc[0]), 0ull);
-    if (fd - fd == 0.0) atomicAdd(&acc[1], -fd); else atomicExch(reinterpret_cast<unsigned long long*>(&acc[1]), 0ull);
-    atomicExch(ticket, 0ull);
-    return true;
-}
-__device__ __forceinline__ void lsnf_publish_stats(double* stats, double sum_ll, double sum_logdet, int rows) {
+__device__ __forceinline__ void lsnf_publish_stats(double* stats, double sum_ll, double sum_logdet, int rows, int lane) {
     const unsigned grid = gridDim.x, wg = blockIdx.x;
-    double fl, fd;
-#ifdef LSNF_STATS_SINGLE     // timing diagnostic: one level for every grid
-    if (false) {
-#else
-    if (grid > LSNF_STATS_SLOTS) {
-#endif
+    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(&stats[2]);
+    int last = 0;
+    if (lane == 0) {
         const unsigned s = wg % LSNF_STATS_SLOTS;
-        const unsigned long long n_s = (grid - s + LSNF_STATS_SLOTS - 1) / LSNF_STATS_SLOTS;       // workgroups of this slot
-        if (!lsnf_stats_add(stats + 8 + 4 * s, sum_ll, sum_logdet, n_s, &fl, &fd)) return;
-        sum_ll = fl; sum_logdet = fd;
-        if (!lsnf_stats_add(stats, sum_ll, sum_logdet, LSNF_STATS_SLOTS, &fl, &fd)) return;
-    } else {
-        if (!lsnf_stats_add(stats, sum_ll, sum_logdet, grid, &fl, &fd)) return;
+        double* sub = stats + 8 + 4 * s;
+        const double r0 = atomicAdd(&sub[0], sum_ll);
+        const double r1 = atomicAdd(&sub[1], sum_logdet);
+        unsigned long long inc = 1ull;
+        asm volatile("" : "+v"(inc) : "v"(r0), "v"(r1));          // the ticket depends on the adds having been performed
+        bool slot_done = true;
+        if (grid > LSNF_STATS_SLOTS) {
+            const unsigned long long n_s = (grid - s + LSNF_STATS_SLOTS - 1) / LSNF_STATS_SLOTS;       // workgroups of this slot
+            unsigned long long* st = reinterpret_cast<unsigned long long*>(&sub[2]);
+            slot_done = atomicAdd(st, inc) == n_s - 1;
+            if (slot_done) atomicExch(st, 0ull);                   // re-arm, fire and forget
+            inc = 1ull;
+        }
+        if (slot_done) {
+            const unsigned long long slots = grid > LSNF_STATS_SLOTS ? LSNF_STATS_SLOTS : grid;
+            if (atomicAdd(ticket, inc) == slots - 1) { last = 1; atomicExch(ticket, 0ull); }
+        }
     }
-    stats[4] = fl; stats[5] = fd; stats[6] = (double)rows;
+    if (__builtin_amdgcn_readfirstlane(last)) {                    // wave-uniform (lane 0 is the first lane)
+        unsigned long long* sub = reinterpret_cast<unsigned long long*>(stats + 8 + 4 * lane);
+        double fl = __longlong_as_double((long long)atomicExch(&sub[0], 0ull));
+        double fd = __longlong_as_double((long long)atomicExch(&sub[1], 0ull));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { fl += __shfl_xor(fl, o, 64); fd += __shfl_xor(fd, o, 64); }
+        if (lane == 0) { stats[4] = fl; stats[5] = fd; stats[6] = (double)rows; }
+    }
 }
 
 // feature offset inside a 32-tile of accumulator register r on lane-half h

@@ -201,10 +201,10 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void lsnf_fwd_kernel(const FwdAr
         double* red = reinterpret_cast<double*>(buf0);
         if (lane == 0) { red[2 * wave] = dl; red[2 * wave + 1] = dd; }
         __syncthreads();
-        if (tid == 0) {
+        if (wave == 0) {         // (all 64 lanes: lsnf_publish_stats is a wave-level protocol)
             double tl = 0.0, td = 0.0;
             for (int w = 0; w < FWD_WAVES; ++w) { tl += red[2 * w]; td += red[2 * w + 1]; }
-            lsnf_publish_stats(a.stats, tl, td, a.B);
+            lsnf_publish_stats(a.stats, tl, td, a.B, lane);
         }
     }
     LSNF_STAMP(40);

@@ -317,10 +317,10 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3_kernel(const Fwd3A
         double* red = reinterpret_cast<double*>(buf0);
         if (lane == 0) { red[2 * wave] = dl; red[2 * wave + 1] = dd; }
         __syncthreads();
-        if (tid == 0) {
+        if (wave == 0) {         // (all 64 lanes: lsnf_publish_stats is a wave-level protocol)
             double tl = 0.0, td = 0.0;
             for (int w = 0; w < F3_WAVES; ++w) { tl += red[2 * w]; td += red[2 * w + 1]; }
-            lsnf_publish_stats(a.stats, tl, td, a.B);
+            lsnf_publish_stats(a.stats, tl, td, a.B, lane);
         }
     }
     F3_STAMP(41, "s_memtime");
@@ -548,10 +548,10 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3b_kernel(const Fwd3
         double* red = reinterpret_cast<double*>(buf0);
         if (lane == 0) { red[2 * wave] = dl; red[2 * wave + 1] = dd; }
         __syncthreads();
-        if (tid == 0) {
+        if (wave == 0) {         // (all 64 lanes: lsnf_publish_stats is a wave-level protocol)
             double tl = 0.0, td = 0.0;
             for (int w = 0; w < F3_WAVES; ++w) { tl += red[2 * w]; td += red[2 * w + 1]; }
-            lsnf_publish_stats(a.stats, tl, td, a.B);
+            lsnf_publish_stats(a.stats, tl, td, a.B, lane);
         }
     }
     F3_STAMP(41, "s_memtime");

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_fwd_kernel(const Small3Arg
             double dl = (live && g == 0) ? (double)ll : 0.0, dd = (live && g == 0) ? (double)el : 0.0;
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) { dl += __shfl_xor(dl, o, 64); dd += __shfl_xor(dd, o, 64); }
-            if (lane == 0) lsnf_publish_stats(a.stats, dl, dd, a.B);
+            lsnf_publish_stats(a.stats, dl, dd, a.B, lane);       // (wave-level protocol: all 64 lanes of wave 0)
         }
     }
 }

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(LSNF_WG_THREADS, 1) void lsnf_small_fwd_kernel(cons
             double dl = (live && h == 0) ? (double)ll : 0.0, dd = (live && h == 0) ? (double)ell : 0.0;
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) { dl += __shfl_xor(dl, o, 64); dd += __shfl_xor(dd, o, 64); }
-            if (lane == 0) lsnf_publish_stats(a.stats, dl, dd, a.B);
+            lsnf_publish_stats(a.stats, dl, dd, a.B, lane);       // (wave-level protocol: all 64 lanes of wave 0)
         }
     }
     SMALL_STAMP(60);
