@@ -638,8 +638,6 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
         __syncthreads();
         if (k + 1 < n_phases) issue_kib<48, NWAVES>(phase_src(k + 1), buf0 + ((k + 1) & 1) * SLOT, wave, lane);
     };
-    issue_kib<48, NWAVES>(phase_src(0), buf0, wave, lane);
-    for (int i = tid; i < a.n_blocks * C::CONST_FLOATS; i += THREADS) cst[i] = a.consts[i];
 
     const int wbase = (blockIdx.x * NWAVES + wave) * (16 * ST);
     int sample[2] = {0, 0}, rows[2] = {0, 0}; bool live[2] = {false, false};
@@ -656,10 +654,15 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
     Tile16 p1, t1;
     float lsum[2] = {0.0f, 0.0f};
     {
+        // the row loads go out FIRST: the constant blocks below travel through registers (load, wait, LDS store), and with that
+        // copy in front the rows were requested one memory round trip (~2 us) later than necessary
         const Tile16 x0 = load_tile16<HT, ST>(0, a.z_in, rows, a.nz, a.half, g, a.vec4);
         const Tile16 x1 = load_tile16<HT, ST>(1, a.z_in, rows, a.nz, a.half, g, a.vec4);
         v[2] = load_tile16<HT, ST>(2, a.z_in, rows, a.nz, a.half, g, a.vec4);
         v[3] = load_tile16<HT, ST>(3, a.z_in, rows, a.nz, a.half, g, a.vec4);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_kib<48, NWAVES>(phase_src(0), buf0, wave, lane);
+        for (int i = tid; i < a.n_blocks * C::CONST_FLOATS; i += THREADS) cst[i] = a.consts[i];
 #pragma unroll
         for (int q = 0; q < 4; ++q) { split_q16<false, ST>(x0, q, xs[0]); split_q16<false, ST>(x1, q, xs[1]); }     // (not hidden: once per launch)
         split_q16<false, ST>(v[2], 0, xs[2]); split_q16<false, ST>(v[2], 1, xs[2]);
