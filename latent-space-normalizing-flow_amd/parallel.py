@@ -115,6 +115,7 @@ class PipelinedStatsReducer:
         self.bucket = bucket
         self.banks = [mk(bucket), mk(bucket)]
         self.work = [None, None]
+        self.pub = [None, None]      # reduced public parts of the banks (multi-rank runs)
         self.bank = 0          # bank being filled
         self.fill = 0          # rows of it handed out and submitted
         self.group = group
@@ -124,18 +125,27 @@ class PipelinedStatsReducer:
         return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
 
     def next_buffer(self) -> torch.Tensor:
-        if self.fill == 0 and self.work[self.bank] is not None:     # first row of a bank whose collective may be in flight
-            self.work[self.bank].wait()
-            self.work[self.bank] = None
+        if self.fill == 0:                                          # first row of a bank whose collective may be in flight
+            self._complete(self.bank)
         return self.banks[self.bank][self.fill]
+
+    def _complete(self, k: int) -> None:
+        """Wait for bank k's collective (a stream-level wait for RCCL) and put the reduced sums back into its rows."""
+        if self.work[k] is not None:
+            self.work[k].wait()
+            self.work[k] = None
+            self.banks[k][:, 4:7].copy_(self.pub[k])
+            self.pub[k] = None
 
     def _flush(self) -> None:
         if self.fill == 0:
             return
         if self._multi():
-            # the whole bank in one message (2 KiB per row): the kernel-internal slots are zero at rest and stay zero; rows of a
-            # partly filled bank (finish() only) that were not written this time carry stale values nobody reads
-            self.work[self.bank] = dist.all_reduce(self.banks[self.bank], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            # only the public part travels: [sum ll, sum logdet, rows] of every row of the bank, gathered into one contiguous
+            # (bucket, 3) message (the rows are LSNF_STATS_DOUBLES wide since ABI v5: 2 KiB each, internal slots included);
+            # rows of a partly filled bank (finish() only) that were not written this time carry stale values nobody reads
+            self.pub[self.bank] = self.banks[self.bank][:, 4:7].contiguous()
+            self.work[self.bank] = dist.all_reduce(self.pub[self.bank], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.bank ^= 1
         self.fill = 0
 
@@ -150,9 +160,7 @@ class PipelinedStatsReducer:
     def finish(self) -> Optional[torch.Tensor]:
         self._flush()                                 # a partly filled bank travels too
         for k in (0, 1):
-            if self.work[k] is not None:
-                self.work[k].wait()
-                self.work[k] = None
+            self._complete(k)
         if self.last is None:
             return None
         b, r = self.last
