@@ -376,7 +376,6 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3b_kernel(const Fwd3
     Pipe3<F3_WAVES> pipe;
     pipe.buf0 = buf0; pipe.slot = C::SLOT3; pipe.wave = wave; pipe.lane = lane;
     pipe.template prime<first_kib(C::P1, C::KT1)>(a.panels3);
-    for (int i = tid; i < a.n_blocks * C::CONST_FLOATS; i += THREADS) cst[i] = a.consts[i];
 
     int sample[2], rows[2]; bool live[2];
 #pragma unroll
@@ -385,6 +384,10 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3b_kernel(const Fwd3
     f32x16 x[NZT];
 #pragma unroll
     for (int t = 0; t < NZT; ++t) x[t] = l16_load_tile<HT>(t, a.z_in, rows, a.nz, a.half, g, a.vec4);
+    __builtin_amdgcn_sched_barrier(0);
+    // (the constant blocks are copied AFTER the row loads have gone out: the copy waits for its loads in order, one memory
+    //  round trip that the rows would otherwise start behind)
+    for (int i = tid; i < a.n_blocks * C::CONST_FLOATS; i += THREADS) cst[i] = a.consts[i];
     float ell[2];
 #pragma unroll
     for (int st = 0; st < 2; ++st) ell[st] = a.objective ? a.objective[rows[st]] : 0.0f;

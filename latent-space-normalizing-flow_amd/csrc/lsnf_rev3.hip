@@ -65,10 +65,6 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_rev3_kernel(const Rev3Args a)
     Pipe3<NW> pipe;
     pipe.buf0 = buf0; pipe.slot = C::SLOT3; pipe.wave = wave; pipe.lane = lane;
     pipe.template prime<first_kib(C::P2, C::KT2)>(a.panels3b + (size_t)last * C::BLOCK3 + C::OFF3_S2);
-    for (int i = tid; i < a.depth * C::CONST_PER_BLOCK; i += 64 * NW) {
-        const int blk = i / C::CONST_PER_BLOCK, r = i % C::CONST_PER_BLOCK;
-        cst[i] = r < C::FWD_CONST ? a.fwd_consts[blk * C::FWD_CONST + r] : a.inv_consts[blk * C::INV_CONST + (r - C::FWD_CONST)];
-    }
 
     const long base = ((long)blockIdx.x * NW + wave) * 32;
     long sample[2], rows[2]; bool live[2];
@@ -78,6 +74,13 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_rev3_kernel(const Rev3Args a)
     f32x16 x[NZT];
 #pragma unroll
     for (int t = 0; t < NZT; ++t) x[t] = l16_load_tile<HT>(t, a.z_in, rows, a.nz, a.half, g, vec4);
+    __builtin_amdgcn_sched_barrier(0);
+    // (the constant blocks are copied AFTER the row loads have gone out: the copy waits for its loads in order, one memory
+    //  round trip that the rows would otherwise start behind)
+    for (int i = tid; i < a.depth * C::CONST_PER_BLOCK; i += 64 * NW) {
+        const int blk = i / C::CONST_PER_BLOCK, r = i % C::CONST_PER_BLOCK;
+        cst[i] = r < C::FWD_CONST ? a.fwd_consts[blk * C::FWD_CONST + r] : a.inv_consts[blk * C::INV_CONST + (r - C::FWD_CONST)];
+    }
     float obj[2];
 #pragma unroll
     for (int st = 0; st < 2; ++st) obj[st] = a.objective ? a.objective[rows[st]] : 0.0f;

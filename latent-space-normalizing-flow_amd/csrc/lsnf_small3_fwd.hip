@@ -73,16 +73,28 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_fwd_kernel(const Small3Arg
 #pragma unroll
     for (int i = 0; i < NU2; ++i) w2[i] = fetch_unit<HT>(a.panels3b + C::OFF3_S2, hw[i] >> 1, hw[i] & 1, lane);
 
-    for (int i = tid; i < a.n_blocks * C::CONST_FLOATS; i += 256) cst[i] = a.consts[i];
-    for (int i = tid; i < 2 * WT * 32; i += 256) MASK[i] = 0u;
-
     const long sample = (long)blockIdx.x * S3_SAMPLES + n;
     const bool live = sample < a.B;
     const long row = live ? sample : (long)a.B - 1;
-    // prologue: z rows -> B-operand tiles of block 0's input
-    for (int hu = wave; hu < 2 * NZT; hu += 4)
-        store_half(XB + (hu >> 1) * S3_BTILE_FLOATS, hu & 1,
-                   load_row_half<HT>(hu >> 1, hu & 1, a.z_in + row * (long)a.nz, a.half, g, a.vec4), lane);
+    // prologue: z rows -> B-operand tiles of block 0's input.  The row loads go out BEFORE the constant blocks are copied:
+    // that copy travels through registers (load, wait, LDS store) and its wait is in order, so with the copy in front the
+    // rows were requested one memory round trip later than necessary
+    constexpr int NHU = (2 * NZT + 3) / 4;
+    f32x4 xrow[NHU];
+#pragma unroll
+    for (int j = 0; j < NHU; ++j) {
+        const int hu = wave + 4 * j;
+        xrow[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (hu < 2 * NZT) xrow[j] = load_row_half<HT>(hu >> 1, hu & 1, a.z_in + row * (long)a.nz, a.half, g, a.vec4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    for (int i = tid; i < a.n_blocks * C::CONST_FLOATS; i += 256) cst[i] = a.consts[i];
+    for (int i = tid; i < 2 * WT * 32; i += 256) MASK[i] = 0u;
+#pragma unroll
+    for (int j = 0; j < NHU; ++j) {
+        const int hu = wave + 4 * j;
+        if (hu < 2 * NZT) store_half(XB + (hu >> 1) * S3_BTILE_FLOATS, hu & 1, xrow[j], lane);
+    }
     float ell = (wave == 0 && a.objective) ? a.objective[row] : 0.0f;      // per-wave partial of the running log-det
     const LsnfActLayout al = lsnf_act_layout(a.B, HT, WT);
     const LsnfDumpLayout dl = lsnf_dump_layout(a.B, a.nz, a.width);

@@ -62,16 +62,18 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_rev_kernel(const Small3Rev
         w2[i] = fetch_unit<HT>(gf_last + C::OFF3_S2, hw[i] >> 1, hw[i] & 1, lane);
         w3[i] = fetch_unit<WT>(gf_last + C::OFF3_S3, hw[i] >> 1, hw[i] & 1, lane);
     }
+    const long sample = (long)blockIdx.x * S3_SAMPLES + n;
+    const bool live = sample < a.B;
+    const long row = live ? sample : (long)a.B - 1;
+    // this wave's half-units of the input; z1 goes to LDS (R2's and I1's operand).  (Requested BEFORE the constant blocks are
+    // copied: that copy waits for its loads in order, i.e. one memory round trip that the rows would otherwise start behind.)
+    f32x4 z1 = load_row_half<HT>(nt1, ft1, a.z_in + row * (long)a.nz, a.half, g, vec4);
+    f32x4 z2 = load_row_half<HT>(HT + nt1, ft1, a.z_in + row * (long)a.nz, a.half, g, vec4);
+    __builtin_amdgcn_sched_barrier(0);
     for (int i = tid; i < a.depth * C::CONST_PER_BLOCK; i += 256) {
         const int blk = i / C::CONST_PER_BLOCK, r = i % C::CONST_PER_BLOCK;
         cst[i] = r < C::FWD_CONST ? a.fwd_consts[blk * C::FWD_CONST + r] : a.inv_consts[blk * C::INV_CONST + (r - C::FWD_CONST)];
     }
-    const long sample = (long)blockIdx.x * S3_SAMPLES + n;
-    const bool live = sample < a.B;
-    const long row = live ? sample : (long)a.B - 1;
-    // this wave's half-units of the input; z1 goes to LDS (R2's and I1's operand)
-    f32x4 z1 = load_row_half<HT>(nt1, ft1, a.z_in + row * (long)a.nz, a.half, g, vec4);
-    f32x4 z2 = load_row_half<HT>(HT + nt1, ft1, a.z_in + row * (long)a.nz, a.half, g, vec4);
     if (has1) store_half(U + nt1 * S3_BTILE_FLOATS, ft1, z1, lane);
     float obj = (wave == 0 && a.objective) ? a.objective[row] : 0.0f;      // per-wave partial
     __syncthreads();
