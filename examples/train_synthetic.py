@@ -56,6 +56,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-graph", action="store_true", help="eager Langevin loop instead of the HIP-graph replay of one step")
     ap.add_argument("--no-tune", action="store_true", help="generator without channels-last / MIOpen find mode")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL, one GPU per rank); gloo lets several "
+                    "ranks SHARE one GPU -- a rehearsal of the data-parallel code path on a one-GPU box, not a measurement")
     args = ap.parse_args()
     size, nz, ngf, f_width, K = GEOMETRY[args.dataset]
     step_size, sigma, nc, B = 0.1, 0.3, 3, args.batch
@@ -63,7 +65,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dev = parallel.pick_device()                                # GPU of LOCAL_RANK (replaces get_free_gpu / nvidia-smi, train.py:708-714)
     torch.cuda.set_device(dev)
-    rank, world, _ = parallel.init_from_env(dev)
+    rank, world, _ = parallel.init_from_env(dev, backend=args.backend)
     torch.manual_seed(1); np.random.seed(1)                     # same initial weights on every rank
     hps = types.SimpleNamespace(f_n_levels=1, f_depth=5, f_flow_permutation=2, f_width=f_width, f_flow_coupling=1)
     netG = make_generator(args.dataset, nz, ngf, nc, not args.no_tune).to(dev)
@@ -72,7 +74,7 @@ def main():
     netF = lsnf_amd._netF(hps, nz=nz).to(dev)
     parallel.broadcast_parameters(netF._param_list())
     if world > 1:
-        netG = nn.parallel.DistributedDataParallel(netG, device_ids=[local_rank])
+        netG = nn.parallel.DistributedDataParallel(netG, device_ids=[dev.index])
     optG = torch.optim.Adam(netG.parameters(), lr=3e-4, betas=(0.5, 0.999))
     try:                                                        # one fused Adam kernel over the flow's 60 tensors
         optF = torch.optim.Adam(netF.parameters(), lr=1e-4, betas=(0.5, 0.999), fused=True)
