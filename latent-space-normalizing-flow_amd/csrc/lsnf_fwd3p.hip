@@ -1,14 +1,16 @@
 // lsnf_fwd3p.hip -- the bf16x3 throughput forward (lsnf_fwd3.hip: fp32-accurate GEMMs as six bf16 MFMAs per product)
 // with its vector work SOFTWARE-PIPELINED under the matrix instructions.
 //
-// Why.  lsnf_fwd3.hip runs "split the inputs -> MFMA the stage -> ReLU / coupling -> split ..." as separate phases, and
-// on gfx950 the vector ALU work of one wave does not run beside the MFMAs of its SIMD partner (tools/micro/stagger.hip:
-// in phase 403 us, partner wave half a phase apart 430 us) -- so the 6 270 VALU instructions per wave (operand split,
-// sigmoid / log epilogue) ADD to the 1 920 MFMAs.  What does overlap is VALU issued by the SAME wave between its own
-// v_mfma_f32_32x32x16_bf16 (32 cycles of pipe time, 8 of issue): tools/micro/stagger.hip measures 2.3 VALU per MFMA
-// hidden to 91 % with the 32x32x16 shape (290 us vs 265 MFMA-only + 152 VALU-only), and hardly at all with 16x16x32
-// (394 us).  So this kernel is the 32x32x16 kernel with every piece of vector work placed, by hand, between the MFMAs
-// of a stage that does not depend on it:
+// Why.  lsnf_fwd3.hip runs "split the inputs -> MFMA the stage -> ReLU / coupling -> split ..." as separate phases, and its
+// 6 270 VALU instructions per wave (operand split, sigmoid / log epilogue) ADD to the 1 920 MFMAs: MFMA-VALU co-execution is
+// 4.7 % of MFMA-busy cycles there (PMC).  Two hardware facts decide what can be done about it (tools/micro/shadow.hip,
+// tools/micro/stagger.hip): (1) an MFMA of either shape holds the SIMD's VALU issue for ~12 cycles -- the
+// 32-cycle 32x32x16 then leaves five 4-cycle slots, the 16-cycle 16x16x32 one; (2) packed fp32 math (v_pk_add_f32 ...) waits
+// for the matrix pipe, so this file is compiled without it (Makefile: -fno-slp-vectorize).  The first kernel below is the
+// 32x32x16 kernel with every piece of vector work placed, by hand, between the MFMAs of a stage that does not depend on it
+// (it needs the fewest cycles, but the chip sustains a ~12 % lower clock under that MFMA shape on real data: opt-in
+// LSNF_MATH_BF16X3_PIPE, the reference point); the second, lsnf_fwd3q_kernel, is the same pipeline on 16x16x32 and the
+// library's default throughput forward:
 //
 //   phase (one LDS weight buffer)   MFMAs   vector work carried between them
 //   S1a  v[0,1]  += Wa^T x           96     block 0: split x[1..3] one k-tile ahead; later blocks (k order 2,0,1,3):
