@@ -248,16 +248,16 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
     hipError_t e;
     const int math = math_mode();
     const bool split = math == LSNF_MATH_BF16X3 || math == LSNF_MATH_BF16X3_32 || math == LSNF_MATH_BF16X3_PIPE || math == LSNF_MATH_BF16X3_PHASED;
-    // Calls without a stash that the software-pipelined forward covers cross over at 4 096 rows, not at the common threshold:
-    // the latency kernel's time is a staircase of 16.5 us per 4 096 rows (one round of 16-row workgroups), lsnf_fwd3q_kernel in
-    // its 16-rows-per-wave form takes 30.5 us up to 16 384 rows (tools/shard_times.py: 17.7 vs 30.2 us at 4 096 rows, 33.6 vs
-    // 30.4 at 6 144, 33.9 vs 30.5 at 8 192, 66 vs 31.7 at 16 384).  Only the AUTO threshold moves (an explicit setting is obeyed);
-    // calls that write a stash keep the common threshold, so that the family that wrote it is the family that reads it
-    // (tools/crossover2.py: 75 vs 69 us at 16 384 rows for those).
+    // Calls without a stash that the software-pipelined forward covers cross over at 8 192 rows, not at the common threshold:
+    // the latency kernel puts 16 / 32 rows on a workgroup up to 4 096 / 8 192 rows (one round of <= 256 workgroups that each
+    // stream the weights once: 14.1 / 20.1 us), lsnf_fwd3q_kernel in its 16-rows-per-wave form takes 30.5 us up to 16 384 rows,
+    // and a 64-row latency workgroup 32.6 us (tools/chk_small3_st.py, tools/shard_times.py, profiles/r03_shard_times.txt).
+    // Only the AUTO threshold moves (an explicit setting is obeyed); calls that write a stash keep the common threshold, so that
+    // the family that wrote it is the family that reads it.
     int small_max = small_batch_max();
-    if (z_saved == nullptr && act_saved == nullptr && small_batch_setting() == LSNF_SMALL_BATCH_AUTO && small_max > 4096 &&
+    if (z_saved == nullptr && act_saved == nullptr && small_batch_setting() == LSNF_SMALL_BATCH_AUTO && small_max > 8192 &&
         math == LSNF_MATH_BF16X3 && g.HT == 2 && g.WT == 2)
-        small_max = 4096;
+        small_max = 8192;
     if (B <= small_max) {
         e = hipErrorInvalidValue;
         if (l16_math())                           // latency forward on the bf16 pipe: 16-sample workgroups (lsnf_small3_fwd.hip)

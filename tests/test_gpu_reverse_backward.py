@@ -167,11 +167,12 @@ def test_full_size_backward_properties(lsnf, gpu_device):
     same_up_to_kinks(gc, g[:B2])
 
 
-def test_default_dispatch_mid_size_batch(lsnf, gpu_device):
-    """Default dispatch at 10 000 rows: the bf16x3 latency forward (16-sample workgroups, L16 lane layout) writes z_saved
-    and the activation stash, the fp32 latency backward (32-sample workgroups, 32x32 layout) reads them -- what travels
-    through HBM is layout-independent."""
-    nz, width, depth, B = 100, 64, 5, 10000
+@pytest.mark.parametrize("B", [5003, 10000, 16383])
+def test_default_dispatch_mid_size_batch(lsnf, gpu_device, B):
+    """Default dispatch between 4 096 and 16 384 rows: the bf16x3 latency forward in its 32- and 64-rows-per-workgroup forms
+    (two / four 16-sample tiles per workgroup, ragged last workgroup: whole tiles past the batch) writes z_saved and the
+    activation stash, the latency backward reads them -- what travels through HBM is layout-independent."""
+    nz, width, depth = 100, 64, 5
     p = O.init_params(nz, width, depth, seed=5)
     plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
     assert lsnf.flow.set_math_mode(-1) == lsnf.flow.MATH_BF16X3 and lsnf.flow.set_small_batch_max(-1) == 16384
