@@ -20,6 +20,15 @@ N > 1: the headline is STRONG scaling -- the 65 536 rows of one e
 over the ranks (`parallel.shard_bounds`), one all-reduce per evaluation -- and the same run also times WEAK scaling
 (65 536 rows per GPU, `--weak-bucket` evaluations per collective) and reports it as `weak_scaling`.
 
+Spread ("median and p10/p90"): the K-step timed region is repeated R = max(5, ceil(200 / K)) times behind ONE
+clock ramp and ONE warm-up; `ms_per_step` is the MEDIAN of the R repetitions, `ms_per_step_p10` / `_p90` ride beside it (same
+for the single-stream figure); the kernel-only loop of the roofline is timed per launch with HIP events and reports its median.
+
+`--shard-of N` (one GPU): what ONE GPU of an N-GPU strong-scaling job does per step -- rows = 65 536 / N, same stream
+rotation, in-kernel sums, the bucket-1 reducer -- next to the full-size step of the same run; prints the per-shard ms/step and
+the N-GPU ceiling it implies (65 536 rows / shard time: no communication, no straggler), i.e. the bound on strong scaling that
+one GPU decides.
+
 Prints ONE JSON line on rank 0, including
   "roofline":     the forward kernel's ALGORITHMIC FLOP/s (327 680 FLOP/sample x rows / HIP-event time of a
                   single-stream kernel-only loop, measured in this run) against the dense peak of the matrix pipe it
@@ -176,6 +185,53 @@ def selftest_ranks(args, rank, world):
     return 0 if ok else 1
 
 
+def shard_mode(args, world, rank, dev, z_full, make_run, timed, summarize, ramp_out, reps, streams, main_stream, dtype):
+    """`--shard-of N`: one GPU's share of an N-GPU strong-scaling step, and the ceiling it implies."""
+    if world != 1:
+        print("--shard-of runs on one GPU", file=sys.stderr)
+        return 2
+    n = args.shard_of
+    if n < 1 or B_GLOBAL % n:
+        print(f"--shard-of {n}: N must divide {B_GLOBAL}", file=sys.stderr)
+        return 2
+    rows = B_GLOBAL // n
+    z = z_full[:rows].contiguous()
+    runs = {"shard": (make_run(z, 1, streams), make_run(z, 1, [main_stream])),
+            "full": (make_run(z_full, 1, streams), make_run(z_full, 1, [main_stream]))}
+    ramp_out(rows), ramp_out(B_GLOBAL)
+    torch.cuda.synchronize()
+    res = {}
+    for name, (multi, single) in runs.items():
+        r = B_GLOBAL // n if name == "shard" else B_GLOBAL
+        res[name] = dict(summarize(timed(multi, args.steps, args.warmup), args.steps, r))
+        res[name].update(summarize(timed(single, args.steps, args.warmup), args.steps, r, prefix="single_stream_"))
+    sh, fu = res["shard"], res["full"]
+    line = {
+        "metric": f"latent-samples/sec through flow+logdet, nz=128: ONE GPU's shard of an {n}-GPU strong-scaling step (65536/{n} rows)",
+        "value": sh["value"], "unit": "latent-samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": sh["ms_per_step"], "ms_per_step_p10": sh["ms_per_step_p10"], "ms_per_step_p90": sh["ms_per_step_p90"],
+        "us_per_step": sh["ms_per_step"] * 1e3, "timed_regions": reps, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "shard_of": n, "rows": rows,
+        "ms_per_step_single_stream": sh["single_stream_ms_per_step"],
+        "ms_per_step_single_stream_p10": sh["single_stream_ms_per_step_p10"],
+        "ms_per_step_single_stream_p90": sh["single_stream_ms_per_step_p90"],
+        "full_size_ms_per_step": fu["ms_per_step"], "full_size_ms_per_step_single_stream": fu["single_stream_ms_per_step"],
+        "full_size_value": fu["value"],
+        # what N such GPUs would deliver with free communication and no straggler: 65 536 rows per shard time
+        "implied_n_gpu_ceiling_samples_per_s": B_GLOBAL / (sh["ms_per_step"] * 1e-3),
+        "implied_speedup_over_1_gpu": fu["ms_per_step"] / sh["ms_per_step"],
+        "implied_speedup_over_1_gpu_single_stream": fu["single_stream_ms_per_step"] / sh["single_stream_ms_per_step"],
+        "untimed_launches_before_timed_region": max(0, args.ramp) + args.warmup,
+        "config": {"workload": f"CIFAR-10 flow prior nz=128 f_width=64 f_depth=5 affine, forward+logdet+log-prob with in-kernel "
+                               f"sums, {rows} of the 65536 synthetic rows of one evaluation (the shard of GPU 0 of {n}); "
+                               f"bucket-1 reducer, no collective (one GPU)",
+                   "streams": len(streams), "clock_ramp_launches_before_warmup": max(0, args.ramp)},
+    }
+    print(json.dumps(line), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,6 +254,10 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: which form is the headline `value` (the other one is timed too and reported beside it)")
     ap.add_argument("--weak-bucket", type=int, default=32, help="evaluations per collective of the weak-scaling figure")
+    ap.add_argument("--shard-of", type=int, default=0, metavar="N",
+                    help="one GPU: time the shard of an N-GPU strong-scaling job (65 536 / N rows per step, same protocol) and "
+                         "print the N-GPU ceiling it implies; the full-size step is timed in the same run")
+    ap.add_argument("--reps", type=int, default=0, help="repetitions of the K-step timed region (default max(5, ceil(200 / K)))")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -250,8 +310,11 @@ def main():
         reducers = [parallel.PipelinedStatsReducer(dev, bucket=bucket) for _ in streams]
         return z, outs, reducers, streams
 
+    reps = args.reps if args.reps > 0 else max(5, -(-200 // max(1, args.steps)))
+
     def timed(run, steps, warmup):
-        """clock ramp (untimed, not steps) + W untimed + K timed steps; returns seconds for the K steps (max over ranks)."""
+        """clock ramp (untimed, not steps) + W untimed steps, then `reps` x (K timed steps); returns the list of seconds per
+        K-step region (max over ranks each)."""
         z, outs, reducers, streams = run
         counter = [0]
 
@@ -267,25 +330,51 @@ def main():
 
         # Clock ramp: MI355X needs ~50 ms of sustained load before it holds its steady shader clock (2.07 GHz in the first
         # ~100 launches, 2.39 GHz afterwards).  The metric is steady-state throughput, so the chip is brought there right
-        # before the W warm-up steps, whatever W is; counted in untimed_launches_before_timed_region.
+        # before the W warm-up steps, whatever W is; counted in untimed_launches_before_timed_region.  The ramp runs on the
+        # main stream into a buffer of its own; the side streams wait for it.
         for _ in range(max(0, args.ramp)):
-            lsnf_amd.forward(plan, z, out=outs[0])
+            lsnf_amd.forward(plan, z, out=ramp_out(z.shape[0]))
+        for s_ in streams:
+            if s_ is not main_stream:
+                s_.wait_stream(main_stream)
         for _ in range(warmup):
             step()
-        fence(reducers, streams)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        fence(reducers, streams)
-        elapsed = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = t.item()
-        return elapsed
+        out = []
+        for _ in range(reps):
+            fence(reducers, streams)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            fence(reducers, streams)
+            elapsed = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed = t.item()
+            out.append(elapsed)
+        return out
+
+    def pct(xs, q):
+        xs = sorted(xs)
+        return xs[min(len(xs) - 1, max(0, int(round(q * (len(xs) - 1)))))]
+
+    def summarize(els, steps, rows_all, prefix=""):
+        med = pct(els, 0.5)
+        return {prefix + "ms_per_step": med / steps * 1e3, prefix + "ms_per_step_p10": pct(els, 0.1) / steps * 1e3,
+                prefix + "ms_per_step_p90": pct(els, 0.9) / steps * 1e3, prefix + "value": rows_all * steps / med}
+
+    _ramp = {}
+
+    def ramp_out(rows):
+        if rows not in _ramp:
+            _ramp[rows] = (torch.empty(rows, NZ, device=dev), torch.empty(rows, device=dev), torch.empty(rows, device=dev))
+        return _ramp[rows]
 
     gen = torch.Generator().manual_seed(1234 + rank)
     z_weak = torch.randn(B_GLOBAL, NZ, generator=gen).to(dev)                  # 65 536 rows on every GPU
+    if args.shard_of:
+        raise SystemExit(shard_mode(args, world, rank, dev, z_weak, make_run, timed, summarize, ramp_out, reps,
+                                    side_streams if n_streams > 1 else [main_stream], main_stream, MODES[args.math]["dtype"]))
     lo, hi = parallel.shard_bounds(B_GLOBAL, world, rank)
     z_strong = z_weak[: hi - lo].contiguous() if world > 1 else z_weak         # this rank's slab of ONE 65 536-row evaluation
     tmp = (torch.empty_like(z_weak), torch.empty(B_GLOBAL, device=dev), torch.empty(B_GLOBAL, device=dev))
@@ -301,38 +390,46 @@ def main():
     for form in forms:
         multi, single, bucket = runs[form]
         z = multi[0]
-        el = timed(multi, args.steps, args.warmup)
-        el1 = timed(single, args.steps, args.warmup)
+        ramp_out(z.shape[0])                          # (allocated before the ramp)
+        els = timed(multi, args.steps, args.warmup)
+        els1 = timed(single, args.steps, args.warmup)
         rows_all = B_GLOBAL if form != "weak" else world * B_GLOBAL
-        results[form] = {"value": rows_all * args.steps / el, "ms_per_step": el / args.steps * 1e3,
-                         "ms_per_step_single_stream": el1 / args.steps * 1e3,
-                         "value_single_stream": rows_all * args.steps / el1,
-                         "rows_per_gpu": z.shape[0], "global_rows_per_step": rows_all,
-                         "evaluations_per_collective": bucket if world > 1 else None}
+        results[form] = dict(summarize(els, args.steps, rows_all))
+        one = summarize(els1, args.steps, rows_all)
+        results[form].update({"ms_per_step_single_stream": one["ms_per_step"], "ms_per_step_single_stream_p10": one["ms_per_step_p10"],
+                              "ms_per_step_single_stream_p90": one["ms_per_step_p90"], "value_single_stream": one["value"],
+                              "timed_regions": reps, "rows_per_gpu": z.shape[0], "global_rows_per_step": rows_all,
+                              "evaluations_per_collective": bucket if world > 1 else None})
     head = results["single"] if world == 1 else results[args.scaling]
 
     # kernel-only loop for the roofline: HIP events on the launch stream around back-to-back launches of one stream
     z1, logdet, ll = tmp
 
-    def kernel_ms(mode):
+    def kernel_ms(mode, spread=None):
+        """single-stream kernel-only loop, one HIP event pair per launch: median launch-to-launch time (ms)"""
         lsnf_amd.flow.set_math_mode(MATH[mode])
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(10):
             lsnf_amd.forward(plan, z_weak, out=(z1, logdet, ll))
         torch.cuda.synchronize()
-        kl = max(50, min(args.steps, 200))
-        e0.record()
-        for _ in range(kl):
+        kl = 200
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(kl + 1)]
+        ev[0].record()
+        for i in range(kl):
             lsnf_amd.forward(plan, z_weak, out=(z1, logdet, ll))
-        e1.record()
+            ev[i + 1].record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / kl
+        ts = [ev[i].elapsed_time(ev[i + 1]) for i in range(kl)]
+        if spread is not None:
+            spread.update({"kernel_ms_p10": pct(ts, 0.1), "kernel_ms_p90": pct(ts, 0.9), "kernel_ms_mean": ev[0].elapsed_time(ev[kl]) / kl,
+                           "launches_timed": kl})
+        return pct(ts, 0.5)
 
     others = {}
     for other in [m for m in ("fp32", "bf16x3", "fp16x2") if m != args.math]:   # the other arithmetic modes, kernel-only
         others[other] = {"kernel_ms": kernel_ms(other)}
         others[other]["ll"] = ll.clone()
-    kern_ms = kernel_ms(args.math)            # also leaves the library in the measured mode
+    kern_spread = {}
+    kern_ms = kernel_ms(args.math, kern_spread)   # also leaves the library in the measured mode
     flops = FLOP_PER_SAMPLE * B_GLOBAL
     for other in others:
         ll_o = others[other].pop("ll")
@@ -378,23 +475,27 @@ def main():
                 traffic = None
         rl = {"bound": "mfma", "achieved": tflops, "peak": mode["peak"], "unit": "TFLOP/s", "frac": tflops / mode["peak"],
               "traffic": traffic, "kernel": mode["kernel"], "pipe": mode["pipe"],
-              "kernel_ms": kern_ms, "flop_per_launch": flops,
+              "kernel_ms": kern_ms, **kern_spread, "flop_per_launch": flops,
               "frac_vs_fp32_mfma_peak": tflops / PEAK_FP32_MFMA_TFLOPS, "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS,
               "matrix_pipe_utilisation": mode["exec_per_alg"] * tflops / mode["peak"],
               "executed_mfma_flops_per_algorithmic_flop": mode["exec_per_alg"],
               "hbm_frac_secondary": BYTES_PER_SAMPLE_FUSED * B_GLOBAL / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-              "note": "achieved = ALGORITHMIC flops (327 680 per sample, SURVEY 8d) / HIP-event time of a single-stream "
-                      "kernel-only loop of this run; frac = achieved / dense peak of the pipe the kernel runs on.  An fp32-"
+              "note": "achieved = ALGORITHMIC flops (327 680 per sample, SURVEY 8d) / MEDIAN per-launch HIP-event time of a single-"
+                      "stream kernel-only loop of this run; frac = achieved / dense peak of the pipe the kernel runs on.  An fp32-"
                       "accurate product costs exec_per_alg MFMAs on that pipe, so frac <= 1/exec_per_alg; "
                       "matrix_pipe_utilisation prices the executed flops",
               "carried": carried}
         line = {
             "metric": "latent-samples/sec through flow+logdet, nz=128 B=65536",
             "value": head["value"], "unit": "latent-samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
-            "scaling": "weak" if world == 1 else args.scaling,
+            "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "ms_per_step_p10": head["ms_per_step_p10"],
+            "ms_per_step_p90": head["ms_per_step_p90"], "timed_regions": reps, "higher_is_better": True,
+            # (strong at every N, N = 1 included: the 65 536 rows of one evaluation are what is fixed)
+            "scaling": "strong" if world == 1 else args.scaling,
             "vs_baseline": None, "dtype": mode["dtype"], "data": "synthetic",
             "ms_per_step_single_stream": head["ms_per_step_single_stream"],
+            "ms_per_step_single_stream_p10": head["ms_per_step_single_stream_p10"],
+            "ms_per_step_single_stream_p90": head["ms_per_step_single_stream_p90"],
             "value_single_stream": head["value_single_stream"],
             "untimed_launches_before_timed_region": max(0, args.ramp) + args.warmup,
             "config": {"workload": "CIFAR-10 flow prior nz=128 f_width=64 f_depth=5 affine, forward+logdet+log-prob, "
