@@ -445,7 +445,8 @@ int lsnf_backward_params(const float* plan, const float* const* params_host, flo
     }
     if (!aligned4(z_in) || !aligned4(z_out) || !aligned4(z_saved) || !aligned4(g_z1) || !aligned4(g_logdet) || !aligned4(g_z_in))
         return fail(LSNF_E_ARG, "lsnf_backward_params: tensors must be 4-byte aligned");
-    const int vec4 = row_vector_width(g, {z_out, g_z_in, z_saved, g_z1});
+    // (z_in too: the batch contraction of block 0 reads its rows with the same vector width)
+    const int vec4 = row_vector_width(g, {z_in, z_out, g_z_in, z_saved, g_z1});
     if (act_saved && !aligned16(act_saved)) return fail(LSNF_E_ARG, "lsnf_backward_params: act_saved must be 16-byte aligned");
     hipError_t e = lsnf_launch_backward_params(g, plan, params_host, grads_host, B, z_in, z_out, z_saved, g_z1, g_logdet,
                                                ll_mode, ll_scale, g_z_in, workspace, vec4, B <= small_batch_max(),

@@ -483,6 +483,10 @@ template <int ST> __device__ __forceinline__ constexpr int unit_st(int q) { retu
 // unit q (optionally through ReLU) -> its dwords of the B operands: 22 (26) VALU per quad
 template <bool RELU, int ST>
 __device__ __forceinline__ void split_q16(const Tile16& x, int q, SplitTile16& out) {
+    // (no contraction: behind the coupling, "x - p1" would become fma(v2 + t, sigma, -p1) and the terms would describe the unrounded
+    //  product instead of the fp32 value that every other kernel -- and the block's stored output -- uses: rows would then depend,
+    //  in their last bits, on which kernel the batch size selects)
+#pragma clang fp contract(off)
     const int ft = q >> 1, st = unit_st<ST>(q), qr = unit_quad<ST>(q);
 #pragma unroll
     for (int jj = 0; jj < ST; ++jj) {

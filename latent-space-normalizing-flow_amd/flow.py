@@ -40,6 +40,18 @@ def _need_cuda(t: torch.Tensor, name: str):
         raise LsnfError(f"{name} must be contiguous")
 
 
+def _check_out(t: torch.Tensor, name: str, need: int, device, dtype=torch.float32, hint: str = ""):
+    """A buffer a kernel writes: on the call's device, of the dtype the kernel stores, contiguous, large enough."""
+    if not t.is_cuda or t.device != device:
+        raise LsnfError(f"{name} must live on {device} (got {t.device})")
+    if t.dtype != dtype:
+        raise LsnfError(f"{name} must be {dtype} (got {t.dtype})")
+    if not t.is_contiguous():
+        raise LsnfError(f"{name} must be contiguous")
+    if t.numel() < need:
+        raise LsnfError(f"{name} has {t.numel()} elements, the kernel writes {need}" + (f" (allocate it {hint})" if hint else ""))
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -152,6 +164,21 @@ def forward(plan: FlowPlan, z: torch.Tensor, objective: Optional[torch.Tensor] =
     saved = z_saved_out                     # caller-owned (n_blocks-1, B, nz) buffer for the block outputs, or
     if saved is None and save_for_backward and n_blocks > 1:
         saved = torch.empty((n_blocks - 1, B, plan.nz), dtype=torch.float32, device=z.device)
+    # The kernels WRITE these caller-owned buffers without knowing their size (the ABI passes pointers): check them here.
+    _check_out(z_out, "out[0] (z_out)", B * plan.nz, z.device)
+    _check_out(logdet, "out[1] (logdet)", B, z.device)
+    if ll is not None:
+        _check_out(ll, "out[2] (ll)", B, z.device)
+    if saved is not None:
+        _check_out(saved, "z_saved", max(n_blocks - 1, 0) * B * plan.nz, z.device)
+    if stats is not None:               # ABI v5: 264 doubles (8 + 64 sub-accumulators of 4); the kernel writes all of them
+        _check_out(stats, "stats", STATS_DOUBLES, z.device, torch.float64, "from new_stats()")
+    if act_saved is not None:
+        _check_out(act_saved, "act_saved", lib.lsnf_act_saved_floats(plan.nz, plan.width, plan.depth, B), z.device,
+                   hint="from new_act_saved()")
+    if params_ws is not None:
+        _check_out(params_ws, "params_ws", lib.lsnf_backward_params_workspace_floats(plan.nz, plan.width, plan.depth, B), z.device,
+                   hint="from new_params_workspace()")
     with torch.cuda.device(z.device):
         rc = lib.lsnf_forward(_ptr(plan.buf), plan.nz, plan.width, plan.depth, plan.coupling, first_block, n_blocks, B,
                               _ptr(z), _ptr(objective), _ptr(z_out), _ptr(logdet), _ptr(ll), _ptr(saved),
@@ -238,11 +265,19 @@ def backward_z(plan: FlowPlan, z_out: torch.Tensor, z_saved: Optional[torch.Tens
     _need_cuda(z_out, "z_out")
     B = z_out.shape[0]
     if act_saved is None and B > 0 and params_fast_path():
-        act_saved = new_act_saved(plan, B, z_out.device)
+        # the rebuilt stash lives on the plan, one per (batch size, device, stream) -- ~1.4 KB per row, not re-allocated per call
+        # (and not inside a graph capture); if the rebuild is refused, lsnf_backward_z recomputes the MLP itself (act_saved NULL)
+        cache = plan.__dict__.setdefault("_restash_buffers", {})
+        key = (B, z_out.device, torch.cuda.current_stream(z_out.device).cuda_stream)
+        buf = cache.get(key)
+        if buf is None:
+            for k in [k for k in cache if k[2] == key[2]]:
+                del cache[k]                 # one batch size at a time per stream
+            buf = cache[key] = new_act_saved(plan, B, z_out.device)
         with torch.cuda.device(z_out.device):
             rc = lib.lsnf_restash(_ptr(plan.buf), plan.nz, plan.width, plan.depth, plan.coupling, B, _ptr(z_out), _ptr(z_saved),
-                                  _ptr(act_saved), _stream_ptr(z_out.device))
-        _lib.check(rc, "lsnf_restash")
+                                  _ptr(buf), _stream_ptr(z_out.device))
+        act_saved = buf if rc == 0 else None
     for name, t in (("z_saved", z_saved), ("g_z1", g_z1), ("g_logdet", g_logdet), ("act_saved", act_saved)):
         if t is not None:
             _need_cuda(t, name)

@@ -273,9 +273,11 @@ class _netF(nn.Module):
         return x, -obj
 
     # ---- fused extras (not in the reference; train.py:316-323 collapsed into two launches) ---------
-    def log_prob(self, z):
-        """(z1, logdet, ll) with ll = -0.5*sum z1^2 + log(2*pi) + logdet (train.py:317-319), one launch."""
-        z1, logdet, ll, _ = flow.forward(self._plan(), z.detach().contiguous(), None, want_ll=True)
+    def log_prob(self, z, stats=None):
+        """(z1, logdet, ll) with ll = -0.5*sum z1^2 + log(2*pi) + logdet (train.py:317-319), one launch.
+        stats: optional buffer from `flow.new_stats()` (or a `PipelinedStatsReducer` row): the launch also leaves
+        [sum ll, sum logdet, rows] in stats[4:7] (train.py:320 -- what a row-sharded evaluation all-reduces)."""
+        z1, logdet, ll, _ = flow.forward(self._plan(), z.detach().contiguous(), None, want_ll=True, stats=stats)
         return z1, logdet, ll
 
     def log_prob_and_grad(self, z, scale=-1.0):

@@ -114,8 +114,13 @@ class PipelinedStatsReducer:
         mk = make_buffer or (lambda n: torch.zeros(n, STATS_DOUBLES, dtype=torch.float64, device=device))
         self.bucket = bucket
         self.banks = [mk(bucket), mk(bucket)]
+        for b in self.banks:             # the forward kernel WRITES whole rows (ABI v5: 264 doubles each): refuse anything else
+            if tuple(b.shape) != (bucket, STATS_DOUBLES) or b.dtype != torch.float64 or not b.is_contiguous():
+                raise ValueError(f"make_buffer(n) must return a contiguous float64 (n, {STATS_DOUBLES}) tensor, got "
+                                 f"{tuple(b.shape)} {b.dtype}")
         self.work = [None, None]
         self.pub = [None, None]      # reduced public parts of the banks (multi-rank runs)
+        self.sent = [0, 0]           # rows of each bank that travelled in its collective
         self.bank = 0          # bank being filled
         self.fill = 0          # rows of it handed out and submitted
         self.group = group
@@ -134,8 +139,9 @@ class PipelinedStatsReducer:
         if self.work[k] is not None:
             self.work[k].wait()
             self.work[k] = None
-            self.banks[k][:, 4:7].copy_(self.pub[k])
-            self.pub[k] = None
+            n = self.sent[k]
+            self.banks[k][:n, 4:7].copy_(self.pub[k])       # only the rows that travelled: a row that was not submitted this
+            self.pub[k] = None                                # round keeps its value (it was reduced once already)
 
     def _flush(self) -> None:
         if self.fill == 0:
@@ -143,8 +149,10 @@ class PipelinedStatsReducer:
         if self._multi():
             # only the public part travels: [sum ll, sum logdet, rows] of every row of the bank, gathered into one contiguous
             # (bucket, 3) message (the rows are LSNF_STATS_DOUBLES wide since ABI v5: 2 KiB each, internal slots included);
-            # rows of a partly filled bank (finish() only) that were not written this time carry stale values nobody reads
-            self.pub[self.bank] = self.banks[self.bank][:, 4:7].contiguous()
+            # of a partly filled bank (finish() only) just the submitted rows: the others hold sums that were reduced in an
+            # earlier round, and reducing them again would multiply them by the world size
+            self.sent[self.bank] = self.fill
+            self.pub[self.bank] = self.banks[self.bank][:self.fill, 4:7].contiguous()
             self.work[self.bank] = dist.all_reduce(self.pub[self.bank], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.bank ^= 1
         self.fill = 0

@@ -89,3 +89,56 @@ def test_two_streams_share_one_plan(lsnf, gpu_device):
     for i in range(2):
         ref = lsnf.forward(plan, zs[i])
         assert torch.equal(outs[i][0], ref[0]) and torch.equal(outs[i][2], ref[2])
+
+
+def test_forward_refuses_undersized_or_foreign_buffers(lsnf, gpu_device):
+    """The kernels write caller-owned buffers through bare pointers: `flow.forward` checks size, dtype and device of each
+    (ABI v5 grew `stats` from 8 to 264 doubles and added the hidden-activation workspace: a buffer of the old layout must
+    raise, not be overrun)."""
+    F = lsnf.flow
+    nz, w, d, B = 32, 16, 2, 40
+    p = O.init_params(nz, w, d, seed=2)
+    plan = lsnf.prepare(lsnf.params_from_state_dict(p, d, gpu_device), nz, w, d)
+    z = torch.randn(B, nz, device=gpu_device)
+    with pytest.raises(lsnf.LsnfError, match="stats"):
+        lsnf.forward(plan, z, stats=torch.zeros(8, dtype=torch.float64, device=gpu_device))
+    with pytest.raises(lsnf.LsnfError, match="stats"):
+        lsnf.forward(plan, z, stats=torch.zeros(F.STATS_DOUBLES, dtype=torch.float32, device=gpu_device))
+    with pytest.raises(lsnf.LsnfError, match="stats"):
+        lsnf.forward(plan, z, stats=torch.zeros(F.STATS_DOUBLES, dtype=torch.float64))
+    act = F.new_act_saved(plan, B, gpu_device)
+    with pytest.raises(lsnf.LsnfError, match="act_saved"):
+        lsnf.forward(plan, z, save_for_backward=True, act_saved=act[: act.numel() // 2])
+    ws = F.new_params_workspace(plan, B, gpu_device)
+    with pytest.raises(lsnf.LsnfError, match="params_ws"):
+        lsnf.forward(plan, z, save_for_backward=True, act_saved=act, params_ws=ws[: ws.numel() - 8])
+    with pytest.raises(lsnf.LsnfError, match="z_out"):
+        lsnf.forward(plan, z, out=(torch.empty(B - 1, nz, device=gpu_device), torch.empty(B, device=gpu_device), torch.empty(B, device=gpu_device)))
+    # and the well-formed call still runs
+    st = F.new_stats(gpu_device)
+    _, _, ll, _ = lsnf.forward(plan, z, save_for_backward=True, act_saved=act, params_ws=ws, stats=st)
+    torch.cuda.synchronize()
+    assert abs(st[4].item() - ll.double().sum().item()) <= 1e-9 * abs(ll.double().sum().item()) and st[6].item() == B
+
+
+@pytest.mark.parametrize("B", [100, 6000])
+def test_parameter_gradients_with_a_4_byte_aligned_z_in(lsnf, gpu_device, B):
+    """The ABI promises 4-byte alignment only: z_in one float off a 16-byte boundary (the batch contraction of block 0 reads
+    its rows) must give the gradients of the aligned call."""
+    F = lsnf.flow
+    nz, w, d = 128, 64, 3
+    p = O.init_params(nz, w, d, seed=3)
+    params = lsnf.params_from_state_dict(p, d, gpu_device)
+    plan = lsnf.prepare(params, nz, w, d)
+    z = torch.randn(B, nz, device=gpu_device)
+    big = torch.empty(B * nz + 1, device=gpu_device)
+    z_off = big[1:].view(B, nz)
+    z_off.copy_(z)
+    assert z_off.data_ptr() % 16 == 4 and z_off.is_contiguous()
+    grads = []
+    for zi in (z, z_off):
+        z1, ld, ll, saved = lsnf.forward(plan, zi, save_for_backward=True)
+        g = F.backward_params(plan, params, zi, z1, saved, ll_scale=-1.0 / B)
+        grads.append([t.clone() for t in g])
+    for a, b in zip(*grads):
+        assert (a - b).norm().item() <= 2e-6 * max(a.norm().item(), 1e-6)

@@ -51,6 +51,18 @@ def _worker(rank, world, port, out):
         red3.submit(st)
     fin3 = red3.finish().clone()
     bank1 = red3.banks[1][:, 4:7].clone()            # evaluations 3, 4, 5, reduced
+    # (1d) a partly filled bank over two finish() cycles: rows that were not submitted again must keep their once-reduced sums
+    red2 = P.PipelinedStatsReducer(torch.device("cpu"), bucket=3)
+    for it in range(4):                               # evaluations 0..2 fill bank 0, evaluation 3 sits alone in bank 1
+        st = red2.next_buffer()
+        st[4], st[5], st[6] = float(ll.sum()) * (it + 1), float(ld.sum()), float(ll.numel())
+        red2.submit(st)
+    red2.finish()
+    st = red2.next_buffer()                           # second cycle: ONE evaluation, into row 0 of bank 0
+    st[4], st[5], st[6] = float(ll.sum()) * 10, float(ld.sum()), float(ll.numel())
+    red2.submit(st)
+    fin2 = red2.finish().clone()
+    bank0_after = red2.banks[0][:, 4:7].clone()      # row 0: evaluation "10" reduced; rows 1, 2: evaluations 1, 2, reduced ONCE
     # (2) broadcast: rank 1 starts from different weights and must end up with rank 0's
     q = O.init_params(NZ, WIDTH, DEPTH, seed=4 + rank)
     live = [q[k] for k in sorted(q) if O.is_live_param(k)]
@@ -65,7 +77,7 @@ def _worker(rank, world, port, out):
     dead = torch.nn.Parameter(torch.zeros(3))            # a parameter without grad must be skipped
     n = P.allreduce_gradients(leaves + [dead], average=False)
     if rank == 0:
-        out.put({"stats": stats.tolist(), "same": same, "n": n, "piped": [p_.tolist() for p_ in piped], "fin": fin.tolist(), "fin3": fin3.tolist(), "bank1": bank1.tolist(), "ll": ll.tolist(), "lo_hi": (lo, hi),
+        out.put({"stats": stats.tolist(), "same": same, "n": n, "piped": [p_.tolist() for p_ in piped], "fin": fin.tolist(), "fin3": fin3.tolist(), "bank1": bank1.tolist(), "fin2": fin2.tolist(), "bank0_after": bank0_after.tolist(), "ll": ll.tolist(), "lo_hi": (lo, hi),
                  "grads": {k: l.grad.numpy().copy() for k, l in zip(keys, leaves)}})
     else:
         out.put({"same": same, "lo_hi": (lo, hi)})
@@ -83,6 +95,15 @@ def test_shard_bounds_cover_and_balance():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         P.shard_bounds(10, 2, 2)
+
+
+def test_reducer_refuses_buffers_of_another_layout():
+    """The forward kernel writes whole 264-double rows (ABI v5): a bank in the 8-double layout of ABI v4 would be overrun."""
+    with pytest.raises(ValueError):
+        P.PipelinedStatsReducer(torch.device("cpu"), make_buffer=lambda n: torch.zeros(n, 8, dtype=torch.float64))
+    with pytest.raises(ValueError):
+        P.PipelinedStatsReducer(torch.device("cpu"), make_buffer=lambda n: torch.zeros(n, P.STATS_DOUBLES, dtype=torch.float32))
+    P.PipelinedStatsReducer(torch.device("cpu"), bucket=2)
 
 
 def test_single_process_is_a_noop():
@@ -118,6 +139,11 @@ def test_two_rank_gloo_matches_full_batch():
     assert abs(r0["fin3"][0] - tot * 7) <= 1e-6 * abs(tot * 7) and r0["fin3"][2] == B
     for j, row in enumerate(r0["bank1"]):
         assert abs(row[0] - tot * (4 + j)) <= 1e-6 * abs(tot * (4 + j)) and row[2] == B
+    # partial final bank over two finish() cycles: the re-submitted row carries the new sums, the others were NOT reduced again
+    assert abs(r0["fin2"][0] - tot * 10) <= 1e-6 * abs(tot * 10) and r0["fin2"][2] == B
+    for j, mult in ((0, 10), (1, 2), (2, 3)):
+        row = r0["bank0_after"][j]
+        assert abs(row[0] - tot * mult) <= 1e-6 * abs(tot * mult) and row[2] == B, (j, row)
     lo, hi = r0["lo_hi"]
     assert torch.allclose(torch.tensor(r0["ll"]), ll[lo:hi], rtol=1e-6, atol=1e-5)
     ref = O.grad_neg_mean_ll_wrt_params(p, z)
