@@ -56,6 +56,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-graph", action="store_true", help="eager Langevin loop instead of the HIP-graph replay of one step")
     ap.add_argument("--no-tune", action="store_true", help="generator without channels-last / MIOpen find mode")
+    ap.add_argument("--phases", action="store_true", help="diagnostic: synchronise after every phase of every iteration and print "
+                    "the per-phase wall time of each (rank 0, stderr); the JSON line then carries their medians")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL, one GPU per rank); gloo lets several "
                     "ranks SHARE one GPU -- a rehearsal of the data-parallel code path on a one-GPU box, not a measurement")
     args = ap.parse_args()
@@ -90,7 +92,16 @@ def main():
         sampler = langevin.GraphedLangevinSampler(netG.module if world > 1 else netG, netF, B, nz, x.shape,
                                                   g_l_step_size=step_size, g_llhd_sigma=sigma, seed=1234, row0=rank * B)
 
+    phase_log = []
+
     def iteration():
+        marks = []
+
+        def mark(name):                                         # --phases: wall time of the phase that just ended
+            if args.phases:
+                torch.cuda.synchronize()
+                marks.append((name, time.perf_counter()))
+        mark("start")
         z0 = torch.randn(B, nz, 1, 1, device=dev, generator=gen)
         gmod = netG.module if world > 1 else netG               # Langevin needs d/dz only: no gradient sync
         # Langevin noise drawn inside the update kernel: one Philox stream for the whole job, keyed by the GLOBAL row
@@ -102,17 +113,29 @@ def main():
         else:
             zk, ggn, gfn, f = langevin.sample_langevin_post_z_with_flow(z0, x, gmod, netF, g_l_steps=K, g_l_step_size=step_size,
                                                                         g_llhd_sigma=sigma, g_l_with_noise=True, philox=noise)
+        mark("langevin_K_steps")
         optG.zero_grad()
         loss_g = mse(netG(zk), x) / B                           # train.py:391-393 (DDP averages the gradients)
+        mark("generator_forward")
         loss_g.backward()
+        mark("generator_backward_incl_ddp_allreduce")
         optG.step()
+        mark("generator_adam")
         optF.zero_grad(set_to_none=True)                        # train.py:404-415, fused: loss and the 60 gradients in 5 launches,
         loss_f = netF.mle_grads(zk.view(B, nz), max_norm=100.0 if world == 1 else None,   # then the one-bucket all-reduce
                                 reuse_buffers=True)
+        mark("flow_mle_grads")
         if world > 1:
             parallel.allreduce_gradients(netF.parameters(), average=True)
+            mark("flow_grad_allreduce")
             torch.nn.utils.clip_grad_norm_(netF.parameters(), 100.0)
         optF.step()
+        mark("flow_clip_adam")
+        if args.phases:
+            row = {b[0]: (b[1] - a[1]) * 1e3 for a, b in zip(marks, marks[1:])}
+            phase_log.append(row)
+            if rank == 0:
+                print(f"iteration {len(phase_log):3d}: " + "  ".join(f"{k} {v:9.2f} ms" for k, v in row.items()), file=sys.stderr, flush=True)
         return loss_g.detach(), loss_f.detach()
 
     def wall(fn, n):
@@ -123,6 +146,17 @@ def main():
         return (time.perf_counter() - t0) / n * 1e3, out
 
     wall(iteration, args.warmup)
+    # MIOpen's find mode searches its solvers the first time a convolution shape is seen -- seconds per shape, and the first
+    # generator BACKWARD brings new shapes (6.2 s in iteration 1 of the two-rank rehearsal, profiles/r03_ddp_svhn_phases.txt).  With a
+    # cold find database, or two ranks searching at once, that can outlast a fixed warm-up (the 12 s/iteration line of
+    # profiles/r02_ddp_rehearsal_gloo.jsonl): warm up until two consecutive iterations agree, then time.
+    settle, prev = 0, None
+    for _ in range(20):
+        t_one, _ = wall(iteration, 1)
+        settle += 1
+        if prev is not None and t_one < 1.5 * prev and prev < 1.5 * t_one:
+            break
+        prev = t_one
     ms_iter, (lg, lf) = wall(iteration, args.iters)
     z2d = torch.randn(B, nz, device=dev); gg = torch.randn(B, nz, device=dev); nn_ = torch.randn(B, nz, device=dev)
     ms_flow, _ = wall(lambda: netF.langevin_step(z2d, gg, nn_, step_size), 200)
@@ -144,7 +178,10 @@ def main():
                           "generator_langevin_grad_ms": ms_gen,
                           "flow_langevin_step_ms": ms_flow, "flow_mle_step_ms": ms_mle,
                           "flow_share_of_iteration": (K * ms_flow + ms_mle) / ms_iter,
-                          "loss_g": lg.item(), "loss_f": lf.item()}), flush=True)
+                          "loss_g": lg.item(), "loss_f": lf.item(), "warmup_iterations": args.warmup + settle,
+                          **({"phase_median_ms": {k: float(np.median([r[k] for r in phase_log[args.warmup:]])) for k in phase_log[0]},
+                              "phases_note": "--phases synchronises after every phase: ms_per_iteration of this run is not a timing"}
+                             if args.phases and phase_log else {})}), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
