@@ -71,7 +71,7 @@ const char* lsnf_last_error(void);
  *   -1                        : query only: returns the threshold in force (a row count)
  * "previous setting" is a row count or LSNF_SMALL_BATCH_AUTO, so `prev = set(x); ...; set(prev)` restores exactly.
  * Under LSNF_SMALL_BATCH_AUTO one kind of call has its own crossover: lsnf_forward WITHOUT z_saved / act_saved in
- * LSNF_MATH_BF16X3 at nz in 66..128, f_width <= 64 switches to the (software-pipelined) throughput kernel above 4096 rows. */
+ * LSNF_MATH_BF16X3 at nz in 66..128, f_width <= 64 switches to the (software-pipelined) throughput kernel above 8192 rows. */
 #define LSNF_SMALL_BATCH_AUTO (-2)
 int lsnf_set_small_batch_max(int rows);
 
@@ -86,12 +86,6 @@ int lsnf_set_small_batch_max(int rows);
  *                      everything else csrc/lsnf_fwd3.hip (separate split / MFMA / epilogue phases).
  *   LSNF_MATH_BF16X3_PHASED : as LSNF_MATH_BF16X3 with every throughput forward on csrc/lsnf_fwd3.hip (comparison, tests).
  *   LSNF_MATH_FP32   : fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere.
- *   LSNF_MATH_BF16X3_32 : the bf16x3 scheme on v_mfma_f32_32x32x16_bf16 in the throughput forward (kept for comparison:
- *                      that shape sustains a lower clock on real data, ~8 % slower); latency forward as LSNF_MATH_FP32.
- *   LSNF_MATH_BF16X3_PIPE : as LSNF_MATH_BF16X3, the throughput forward (calls without stash / block outputs, nz > 64,
- *                      width <= 64) on the 32x32x16 form of that pipeline (lsnf_fwd3p_kernel).  Fewer cycles, but the chip
- *                      sustains a ~12 % lower clock under that MFMA shape: measured slower than LSNF_MATH_BF16X3
- *                      (DESIGN.md section 5); kept as the reference point for that finding.
  *   LSNF_MATH_FP16X2 : (opt-in; NARROWER than the reference's fp32: 11 + 11 operand bits) throughput forward and reverse
  *                      with both operands split into two fp16 terms, three fp16 MFMAs per product (csrc/lsnf_fwd2h.hip;
  *                      dropped terms <= 2^-22 |w||x|; operands below 2^-3 in magnitude additionally carry an ABSOLUTE
@@ -104,12 +98,11 @@ int lsnf_set_small_batch_max(int rows);
  *                      computation's are.  In-place calls (z_out == z_in) and calls with in-kernel batch sums (`stats`)
  *                      run LSNF_MATH_BF16X3 directly.  Every other kernel (latency kernels, backward) as LSNF_MATH_BF16X3.
  * mode < 0 only queries.  Returns the previous mode (default LSNF_MATH_DEFAULT, or the LSNF_MATH environment
- * variable "fp32" / "bf16x3" / "bf16x3_32" / "bf16x3_pipe" / "fp16x2"). */
+ * variable "fp32" / "bf16x3" / "bf16x3_phased" / "fp16x2").  (Values 2 and 4 -- the same scheme on v_mfma_f32_32x32x16_bf16, phase-separated /
+ * software-pipelined, both measured slower -- exist only in research builds, -DLSNF_EXPERIMENTAL_KERNELS; refused otherwise.) */
 #define LSNF_MATH_FP32 0
 #define LSNF_MATH_BF16X3 1
-#define LSNF_MATH_BF16X3_32 2
 #define LSNF_MATH_FP16X2 3
-#define LSNF_MATH_BF16X3_PIPE 4
 #define LSNF_MATH_BF16X3_PHASED 5
 #define LSNF_MATH_DEFAULT LSNF_MATH_BF16X3
 int lsnf_set_math_mode(int mode);

@@ -15,6 +15,16 @@
 #include "../../include/lsnf_flow.h"
 #include "lsnf_layout.h"
 
+// Research builds (-DLSNF_EXPERIMENTAL_KERNELS) also carry the bf16x3 scheme on v_mfma_f32_32x32x16_bf16 -- phase-separated (2)
+// and software-pipelined (4) -- both measured slower than the 16x16x32 kernels (profiles/HISTORY.md); not part of the ABI.
+#define LSNF_MATH_X_BF16X3_32 2
+#define LSNF_MATH_X_BF16X3_PIPE 4
+#ifdef LSNF_EXPERIMENTAL_KERNELS
+#define LSNF_HAVE_X 1
+#else
+#define LSNF_HAVE_X 0
+#endif
+
 // kernel launchers (other translation units)
 hipError_t lsnf_launch_prepare(const LsnfGeo& g, const float* const* params_host, float* plan, void* scratch, hipStream_t stream);
 size_t lsnf_prep_scratch_bytes(int nz, int depth);
@@ -103,7 +113,7 @@ int row_vector_width(const LsnfGeo& g, std::initializer_list<const void*> rows) 
 }
 bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
 
-// arithmetic of the GEMMs (LSNF_MATH=fp32|bf16x3|bf16x3_phased|bf16x3_32|bf16x3_pipe|fp16x2 overrides the default).  The two knobs are
+// arithmetic of the GEMMs (LSNF_MATH=fp32|bf16x3|bf16x3_phased|fp16x2 overrides the default).  The two knobs are
 // process-wide settings read by every call: atomics, so that a setter on one thread and a launch on another do not race
 // (a launch sees the old or the new value, never a torn one).
 std::atomic<int> g_math{-1};
@@ -111,9 +121,10 @@ int math_mode() {
     int m = g_math.load(std::memory_order_relaxed);
     if (m < 0) {
         const char* e = getenv("LSNF_MATH");
-        m = (e && !strcmp(e, "bf16x3")) ? LSNF_MATH_BF16X3 : (e && !strcmp(e, "bf16x3_32")) ? LSNF_MATH_BF16X3_32
-          : (e && !strcmp(e, "bf16x3_pipe")) ? LSNF_MATH_BF16X3_PIPE : (e && !strcmp(e, "bf16x3_phased")) ? LSNF_MATH_BF16X3_PHASED
-          : (e && !strcmp(e, "fp16x2")) ? LSNF_MATH_FP16X2 : (e && !strcmp(e, "fp32")) ? LSNF_MATH_FP32 : LSNF_MATH_DEFAULT;
+        m = (e && !strcmp(e, "bf16x3")) ? LSNF_MATH_BF16X3 : (e && !strcmp(e, "bf16x3_phased")) ? LSNF_MATH_BF16X3_PHASED
+          : (e && !strcmp(e, "fp16x2")) ? LSNF_MATH_FP16X2 : (e && !strcmp(e, "fp32")) ? LSNF_MATH_FP32
+          : (LSNF_HAVE_X && e && !strcmp(e, "bf16x3_32")) ? LSNF_MATH_X_BF16X3_32
+          : (LSNF_HAVE_X && e && !strcmp(e, "bf16x3_pipe")) ? LSNF_MATH_X_BF16X3_PIPE : LSNF_MATH_DEFAULT;
         int expected = -1;
         g_math.compare_exchange_strong(expected, m, std::memory_order_relaxed);
         m = g_math.load(std::memory_order_relaxed);
@@ -144,7 +155,7 @@ int small_batch_max() {
     return math_mode() == LSNF_MATH_FP16X2 ? 12288 : LSNF_SMALL_MAX_DEFAULT;
 }
 // modes whose latency / backward / reverse kernels are the bf16x3 "L16" ones
-bool l16_math() { const int m = math_mode(); return m == LSNF_MATH_BF16X3 || m == LSNF_MATH_FP16X2 || m == LSNF_MATH_BF16X3_PIPE || m == LSNF_MATH_BF16X3_PHASED; }
+bool l16_math() { const int m = math_mode(); return m == LSNF_MATH_BF16X3 || m == LSNF_MATH_FP16X2 || m == LSNF_MATH_X_BF16X3_PIPE || m == LSNF_MATH_BF16X3_PHASED; }
 
 int geo_or_fail(LsnfGeo* g, int nz, int width, int depth, int coupling) {
     if (lsnf_geo_init(g, nz, width, depth, coupling))
@@ -167,8 +178,8 @@ int lsnf_set_small_batch_max(int rows) {
 }
 int lsnf_set_math_mode(int mode) {
     const int prev = math_mode();
-    if (mode == LSNF_MATH_FP32 || mode == LSNF_MATH_BF16X3 || mode == LSNF_MATH_BF16X3_32 || mode == LSNF_MATH_FP16X2 ||
-        mode == LSNF_MATH_BF16X3_PIPE || mode == LSNF_MATH_BF16X3_PHASED)
+    if (mode == LSNF_MATH_FP32 || mode == LSNF_MATH_BF16X3 || mode == LSNF_MATH_FP16X2 || mode == LSNF_MATH_BF16X3_PHASED ||
+        (LSNF_HAVE_X && (mode == LSNF_MATH_X_BF16X3_32 || mode == LSNF_MATH_X_BF16X3_PIPE)))
         g_math.store(mode, std::memory_order_relaxed);
     return prev;
 }
@@ -247,7 +258,7 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
     // crossover, throughput kernel (128 rows per workgroup, weights shared through LDS) above it
     hipError_t e;
     const int math = math_mode();
-    const bool split = math == LSNF_MATH_BF16X3 || math == LSNF_MATH_BF16X3_32 || math == LSNF_MATH_BF16X3_PIPE || math == LSNF_MATH_BF16X3_PHASED;
+    const bool split = math == LSNF_MATH_BF16X3 || math == LSNF_MATH_X_BF16X3_32 || math == LSNF_MATH_X_BF16X3_PIPE || math == LSNF_MATH_BF16X3_PHASED;
     // Calls without a stash that the software-pipelined forward covers cross over at 8 192 rows, not at the common threshold:
     // the latency kernel puts 16 / 32 rows on a workgroup up to 4 096 / 8 192 rows (one round of <= 256 workgroups that each
     // stream the weights once: 14.1 / 20.1 us), lsnf_fwd3q_kernel in its 16-rows-per-wave form takes 30.5 us up to 16 384 rows,
@@ -284,12 +295,12 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
         if (math == LSNF_MATH_BF16X3 && !hdump)        // vector work software-pipelined under 16x16x32 MFMAs (lsnf_fwd3p.hip, lsnf_fwd3q_kernel)
             e = lsnf_launch_forward3q(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
                                       z_saved, act_saved, stats, vec4, (hipStream_t)stream);
-        if (math == LSNF_MATH_BF16X3_PIPE && !hdump)   // the 32x32x16 kernel with its vector work pipelined under the MFMAs (lsnf_fwd3p.hip)
+        if (math == LSNF_MATH_X_BF16X3_PIPE && !hdump) // (research builds) the 32x32x16 kernel with its vector work pipelined under the MFMAs
             e = lsnf_launch_forward3p(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
                                       z_saved, act_saved, stats, vec4, (hipStream_t)stream);
         if (e == hipErrorInvalidValue && (split || math == LSNF_MATH_FP16X2))   // error-free split on the bf16 matrix pipe (lsnf_fwd3.hip)
             e = lsnf_launch_forward3(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
-                                     z_saved, act_saved, stats, vec4, math != LSNF_MATH_BF16X3_32, /*fixup=*/0, (hipStream_t)stream, hdump);
+                                     z_saved, act_saved, stats, vec4, math != LSNF_MATH_X_BF16X3_32, /*fixup=*/0, (hipStream_t)stream, hdump);
         if (e == hipErrorInvalidValue && !hdump)  // fp32 MFMA kernel (also: stacks too deep for fwd3's LDS budget)
             e = lsnf_launch_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
                                     z_saved, act_saved, stats, vec4, (hipStream_t)stream);

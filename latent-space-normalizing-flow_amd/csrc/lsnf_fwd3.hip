@@ -62,7 +62,7 @@ struct Fwd3Args {
 #define F3_STAMP(i, INSN) do {} while (0)
 #endif
 
-#if LSNF_L16_PARTS == 3   // the 32x32x16 variant exists for the bf16x3 split only
+#if LSNF_L16_PARTS == 3 && defined(LSNF_EXPERIMENTAL_KERNELS)   // the 32x32x16 comparison kernel: bf16x3 split, research builds only
 
 // registers 8*s .. 8*s+7 of an activation tile -> x1, x2, x3 of k-step s
 __device__ __forceinline__ void split_kstep(const f32x16& x, int s, Split3& out) {
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3_kernel(const Fwd3A
     F3_STAMP(51, "s_memrealtime");
 }
 
-#endif  // LSNF_L16_PARTS == 3
+#endif  // LSNF_L16_PARTS == 3 && LSNF_EXPERIMENTAL_KERNELS
 
 // =====================================================================================================================
 // The same kernel on v_mfma_f32_16x16x32_bf16 ("L16" lane layout of lsnf_layout.h: a wave's 32 samples are two sample
@@ -565,7 +565,7 @@ template <class C, int F3_WAVES>
 hipError_t launch_fwd3_w(const Fwd3Args& a, hipStream_t stream) {
     const size_t lds = ((size_t)a.n_blocks * C::CONST_FLOATS + 2 * (size_t)C::SLOT3) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-#if LSNF_L16_PARTS == 3
+#if LSNF_L16_PARTS == 3 && defined(LSNF_EXPERIMENTAL_KERNELS)
     auto kern = a.shape16 ? lsnf_fwd3b_kernel<C, F3_WAVES> : lsnf_fwd3_kernel<C, F3_WAVES>;
 #else
     auto kern = lsnf_fwd3b_kernel<C, F3_WAVES>;
@@ -601,6 +601,9 @@ hipError_t LSNF_FWD3_ENTRY(const LsnfGeo& g, const float* plan, int first_block,
     if (hdump && !shape16) return hipErrorInvalidValue;      // (the dump is written by the L16 kernels)
     a.fixup = fixup;
     a.guard = reinterpret_cast<const unsigned*>(plan + g.off_guard);
+#if !defined(LSNF_EXPERIMENTAL_KERNELS)
+    if (!shape16) return hipErrorInvalidValue;               // the 32x32x16 comparison kernel is not in this build
+#endif
 #if LSNF_L16_PARTS == 3
     if (fixup && !shape16) return hipErrorInvalidValue;      // the fix-up pass is the L16 kernel
     if (fixup && stats) return hipErrorInvalidValue;         // (a partial recomputation cannot repair in-kernel batch sums)

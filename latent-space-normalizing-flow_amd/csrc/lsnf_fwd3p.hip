@@ -72,15 +72,20 @@ struct Fwd3pCfg : LsnfStackCfg<2, WT_> {
     static constexpr int CONST_FLOATS = S::FWD_CONST;
 };
 
-// the three bf16 terms of one activation tile, B-operand order: w[s][part] = k-step s (registers 8s..8s+7)
-struct SplitTile { unsigned d[2][3][4]; };    // scalars, assembled into the 128-bit operand at the MFMA: a partial write
-                                               // of a register TUPLE keeps the whole old tuple alive (measured: +170 VGPRs)
-
 // Vector work whose results are consumed only by a LATER phase would be sunk out of the MFMA region it is meant to hide
 // under (instruction selection orders pure arithmetic by use, not by source position; sched_barrier constrains the machine
 // scheduler only): an empty volatile asm that reads the results pins them to the step that computed them.
 __device__ __forceinline__ void keep(unsigned a, unsigned b, unsigned c) { asm volatile("" :: "v"(a), "v"(b), "v"(c)); }
 __device__ __forceinline__ void keep(float a, float b, float c, float d, float e) { asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d), "v"(e)); }
+
+// ---- one MFMA group: acc += A(frag) * x(k-step) for the six kept terms, with V VALU pinned behind every MFMA ----------
+struct StepDesc { int acc, tile, s, frag; };     // accumulator index, input tile, k-step, fragment offset (bf16x8 units / 64)
+template <int KT> constexpr StepDesc mkstep(int acc, int tl, int in_tile, int kt, int s) { return StepDesc{acc, in_tile, s, ((tl * KT + kt) * 2 + s) * 3}; }
+
+#ifdef LSNF_EXPERIMENTAL_KERNELS   // the 32x32x16 form of the pipeline (research builds: LSNF_MATH value 4), measured slower than the 16x16x32 form
+// the three bf16 terms of one activation tile, B-operand order: w[s][part] = k-step s (registers 8s..8s+7)
+struct SplitTile { unsigned d[2][3][4]; };    // scalars, assembled into the 128-bit operand at the MFMA: a partial write
+                                               // of a register TUPLE keeps the whole old tuple alive (measured: +170 VGPRs)
 
 // registers 4q..4q+3 of `x` (optionally through ReLU) -> dwords 2(q&1), 2(q&1)+1 of k-step q>>1: 18 (22) VALU
 template <bool RELU>
@@ -119,10 +124,6 @@ __device__ __forceinline__ void couple_quad(f32x16& v, const f32x16& t, const f3
 #pragma unroll
     for (int r = 4 * q; r < 4 * q + 4; ++r) v[r] = (v[r] + t[r]) * sig[r];
 }
-
-// ---- one MFMA group: acc += A(frag) * x(k-step) for the six kept terms, with V VALU pinned behind every MFMA ----------
-struct StepDesc { int acc, tile, s, frag; };     // accumulator index, input tile, k-step, fragment offset (bf16x8 units / 64)
-template <int KT> constexpr StepDesc mkstep(int acc, int tl, int in_tile, int kt, int s) { return StepDesc{acc, in_tile, s, ((tl * KT + kt) * 2 + s) * 3}; }
 
 template <int V>
 __device__ __forceinline__ void pin6() {
@@ -396,6 +397,8 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3p_kernel(const Fwd3pA
     P_STAMP(51, "s_memrealtime");
 }
 
+#endif  // LSNF_EXPERIMENTAL_KERNELS
+
 // =====================================================================================================================
 // The same pipeline on v_mfma_f32_16x16x32_bf16 (the "L16" lane layout of lsnf_l16.h, the weights of plan region
 // off_f3b_panels).  Why a second form: the 32x32x16 kernel above needs fewer cycles than lsnf_fwd3b_kernel but the chip
@@ -531,6 +534,7 @@ __device__ __forceinline__ void pin_mfma() {       // NM MFMAs, NV VALU spread b
 // StepDesc here: acc = output tile, s = its 16-feature half ft, tile = input k-tile, frag as above
 template <class PH, int ST, class Fill, class Mid>
 __device__ __forceinline__ void run_phase16(Tile16* acc, const float* bias_ptr /* bias_lane_ptr of the block */, const SplitTile16* in, const float* lbuf, int lane, Fill&& fill, Mid&& mid) {
+    // mid(ic): called at the head of every step (the kernel spreads the next phase's weight DMA over the steps there)
     const bf16x8* wp = reinterpret_cast<const bf16x8*>(lbuf) + lane;
     __builtin_amdgcn_sched_barrier(0);
     bf16x8 a[3];
@@ -541,7 +545,7 @@ __device__ __forceinline__ void run_phase16(Tile16* acc, const float* bias_ptr /
     lsnf_static_for<PH::N>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr StepDesc d = PH::at(i);
-        if constexpr (i == PH::MID) { mid(); __builtin_amdgcn_sched_barrier(0); }
+        mid(ic);
         bf16x8 na[3];
         f32x4v nbq = bq;
 #pragma unroll
@@ -581,14 +585,14 @@ __device__ __forceinline__ void run_phase16(Tile16* acc, const float* bias_ptr /
 // under S1b) is simply kept -- no second split; x[2]'s split is finished under steps 0-1, then sigmoid(p1) (2-5), the coupling
 // of x[3] (6-7) and its split (8-11: k-tile 3 starts at step 12) of the previous block
 struct QhS1a {
-    static constexpr int N = 16, MID = 8;
+    static constexpr int N = 16;
     static constexpr int btile(int acc) { return acc; }
     static constexpr StepDesc at(int i) { return mkstep<4>((i >> 1) & 1, (i >> 1) & 1, i >> 2, i >> 2, i & 1); }
     static constexpr int valu(int i) { return i < 2 ? 22 : (i < 6 ? 28 : (i < 8 ? 16 : (i < 12 ? 22 : 0))); }
 };
 // S1b: v[2], v[3]; split v[0], v[1] (S2's input and the next block's x[0], x[1]) under the last eight steps
 struct QhS1b {
-    static constexpr int N = 16, MID = 8;
+    static constexpr int N = 16;
     static constexpr int btile(int acc) { return 2 + acc; }
     static constexpr StepDesc at(int i) { return mkstep<4>((i >> 1) & 1, (i >> 1) & 1, i >> 2, i >> 2, i & 1); }
     static constexpr int valu(int i) { return i >= 8 ? 22 : 0; }
@@ -596,7 +600,7 @@ struct QhS1b {
 // S2 + S3 out of one buffer [h1_0][h1_1][h2_0][h2_1].  S2 n-major (h1[0] is complete after step 3 and is split under h1[1]'s
 // steps 4-7), S3 k-major (h1[1] is split under its k-tile-0 steps 8-11; h2's halves complete at steps 12..15)
 struct QhS23 {
-    static constexpr int N = 16, MID = 8;
+    static constexpr int N = 16;
     static constexpr int btile(int acc) { return 4 + acc; }                 // P1 = 4 (nz in 66..128)
     static constexpr StepDesc at(int i) {
         if (i < 8) { const int tl = i >> 2, kt = (i >> 1) & 1; return mkstep<2>(tl, tl, kt, kt, i & 1); }
@@ -608,7 +612,7 @@ struct QhS23 {
 // S4 out of one buffer [t0][t1][p0][p1]: k-tile 0 of all four tiles first (h2[1]'s split hides there), then k-tile 1 in the
 // order p0, t0, p1, t1
 struct QhS4 {
-    static constexpr int N = 16, MID = 8;
+    static constexpr int N = 16;
     static constexpr int btile(int acc) { return 8 + (acc == 0 ? 2 : (acc == 1 ? 0 : (acc == 2 ? 3 : 1))); }    // P1 + P2 + P3 = 8; accumulators p0, t0, p1, t1
     static constexpr int torder(int j) { return j == 0 ? 2 : (j == 1 ? 0 : (j == 2 ? 3 : 1)); }     // p0, t0, p1, t1 (buffer tiles)
     static constexpr StepDesc at(int i) { const int kt = i >> 3, j = (i >> 1) & 3; return mkstep<2>(j, torder(j), kt, kt, i & 1); }
@@ -639,10 +643,29 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
         const int j = k & 3;
         return gb + (j == 0 ? 0 : (j == 1 ? 2 * 4 * F : (j == 2 ? C::OFF3_S2 : C::OFF3_S4)));
     };
+    // Barrier k: my pieces of phase k's weights have landed (vmcnt), everybody's have (barrier), and buffer (k + 1) & 1 is free.
+    // The next phase's 48 KiB are NOT issued here in one burst (12 / 6 LDS-DMA instructions per wave, each with its m0
+    // hand-over: ~1 200 cycles per phase with one wave per SIMD, tools/stamps_fwd3p.py at 16 384 rows) but one piece at the head
+    // of a step of phase k (dma_step), where the issue overlaps the step's MFMAs.  The last phase re-fetches its own weights into
+    // the free buffer -- no DMA under a branch; the epilogue waits for it before LDS is reused or released.
     auto sync_issue = [&](int k) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#ifdef LSNF_FWD3Q_BURST_DMA
         if (k + 1 < n_phases) issue_kib<48, NWAVES>(phase_src(k + 1), buf0 + ((k + 1) & 1) * SLOT, wave, lane);
+#endif
+    };
+    constexpr int PER_WAVE = 48 / NWAVES, EVERY = 16 / PER_WAVE;         // pieces per wave and phase; one every EVERY steps
+    const float* dma_src = nullptr; float* dma_dst = nullptr;
+    auto dma_arm = [&](int k) {                                          // phase k is about to run: its steps carry phase k+1's pieces
+        dma_src = phase_src(k + 1 < n_phases ? k + 1 : k);
+        dma_dst = buf0 + ((k + 1) & 1) * SLOT;
+    };
+    auto dma_step = [&](auto ic) {
+#ifndef LSNF_FWD3Q_BURST_DMA
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i % EVERY == 0 && i / EVERY < PER_WAVE) issue_piece<NWAVES>(dma_src, dma_dst, i / EVERY, wave, lane);
+#endif
     };
 
     const int wbase = (blockIdx.x * NWAVES + wave) * (16 * ST);
@@ -697,23 +720,25 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
         {
             const float* bv = bias_lane_ptr(cb, g);
             if (k0 > 0) sync_issue(k0);
+            dma_arm(k0);
             run_phase16<QhS1a, ST>(v, bv, xs, buf0 + (k0 & 1) * SLOT, lane, [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 if constexpr (i < 2) split_q16<false, ST>(v[2], 2 + i, xs[2]);                 // x[2]: k-tile 2 starts at step 8
                 else if constexpr (i < 6) sigmoid_q16<ST>(p1, i - 2, lsum);
                 else if constexpr (i < 8) { couple_q16<ST>(v[3], t1, p1, 2 * (i - 6)); couple_q16<ST>(v[3], t1, p1, 2 * (i - 6) + 1); }
                 else if constexpr (i < 12) split_q16<false, ST>(v[3], i - 8, xs[3]);           // x[3]: k-tile 3 starts at step 12
-            }, [] {});
+            }, dma_step);
         }
         if (blk == 1) P_STAMP(11, "s_memtime");
         // ---- S1b: v[2,3]; split v[0], v[1]: S2's input AND the next block's x[0], x[1] ----
         {
             const float* bv = bias_lane_ptr(cb, g);
             sync_issue(k0 + 1);
+            dma_arm(k0 + 1);
             run_phase16<QhS1b, ST>(v + 2, bv, xs, buf0 + ((k0 + 1) & 1) * SLOT, lane, [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 if constexpr (i >= 8) split_q16<false, ST>(v[(i - 8) >> 2], i & 3, vh[(i - 8) >> 2]);    // (xs[0], xs[1] are dead by now: k order)
-            }, [] {});
+            }, dma_step);
         }
         if (blk == 1) P_STAMP(12, "s_memtime");
         if (!more) {             // last block: the v1 half is final (model.py:422) -- its stores drain under S2..S4
@@ -739,12 +764,13 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
             static_assert(C::P1 == 4 && C::P2 == 2 && C::P3 == 2, "bias tile indices of the phase tables");
             const float* bv = bias_lane_ptr(cb, g);
             sync_issue(k0 + 2);
+            dma_arm(k0 + 2);
             run_phase16<QhS23, ST>(hh, bv, vh, buf0 + ((k0 + 2) & 1) * SLOT, lane, [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 if constexpr (i >= 4 && i < 8) split_q16<true, ST>(hh[0], i - 4, vh[2]);      // h1[0] under h1[1]'s steps
                 if constexpr (i >= 8 && i < 12) split_q16<true, ST>(hh[1], i - 8, vh[3]);     // h1[1] under S3's k-tile 0
                 if constexpr (i >= 13) split_q16<true, ST>(hh[2], i - 13, h2s[0]);             // h2[0]: its halves complete after steps 12, 13
-            }, [] {});
+            }, dma_step);
         }
         if (blk == 1) P_STAMP(13, "s_memtime");
         xs[0] = vh[0]; xs[1] = vh[1];            // v1 is the next block's first half (model.py:422): its split is kept
@@ -755,6 +781,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
             const float* bv = bias_lane_ptr(cb, g);
             split_q16<true, ST>(hh[2], 3, h2s[0]);       // (the last quad of h2[0]: exposed, S4's first step needs it)
             sync_issue(k0 + 3);
+            dma_arm(k0 + 3);
             run_phase16<QhS4, ST>(tp, bv, h2s, buf0 + ((k0 + 3) & 1) * SLOT, lane, [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 if constexpr (i < 4) split_q16<true, ST>(hh[3], i, h2s[1]);                    // h2[1] under k-tile 0
@@ -763,7 +790,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
                 if constexpr (i == 12) couple_q16<ST>(v[2], tp[1], tp[0], 0);
                 if constexpr (i == 13) { couple_q16<ST>(v[2], tp[1], tp[0], 1); couple_q16<ST>(v[2], tp[1], tp[0], 2); couple_q16<ST>(v[2], tp[1], tp[0], 3); }
                 if constexpr (i >= 14) split_q16<false, ST>(v[2], i - 14, xs[2]);
-            }, [] {});
+            }, dma_step);
             p1 = tp[2]; t1 = tp[3];              // (the rest of the coupling rides under the next block's S1a)
         }
         if (blk == 1) P_STAMP(14, "s_memtime");
@@ -800,6 +827,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
             if (a.ll_out) a.ll_out[smp] = ll[st];
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the last phase's trailing weight DMA: before LDS is reused below or released)
     if (a.stats) {
         double dl = 0.0, dd = 0.0;
 #pragma unroll
@@ -834,6 +862,7 @@ hipError_t launch_fwd3q_w(const Fwd3pArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+#ifdef LSNF_EXPERIMENTAL_KERNELS
 template <int WT, int NWAVES>
 hipError_t launch_fwd3p_w(const Fwd3pArgs& a, hipStream_t stream) {
     using C = Fwd3pCfg<WT>;
@@ -846,6 +875,7 @@ hipError_t launch_fwd3p_w(const Fwd3pArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NWAVES), lds, stream, a);
     return hipGetLastError();
 }
+#endif
 }  // namespace
 
 // host-side dispatcher (called from lsnf_api.hip); hipErrorInvalidValue = this call is not covered (geometry, or the
@@ -853,6 +883,9 @@ hipError_t launch_fwd3p_w(const Fwd3pArgs& a, hipStream_t stream) {
 hipError_t lsnf_launch_forward3p(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                  const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                  float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4, hipStream_t stream) {
+#ifndef LSNF_EXPERIMENTAL_KERNELS
+    return hipErrorInvalidValue;         // (not in this build)
+#else
     if (g.HT != 2 || g.WT != 2 || z_saved != nullptr || act_saved != nullptr) return hipErrorInvalidValue;
     Fwd3pArgs a;
     a.consts = plan + g.off_fwd_const + (size_t)first_block * g.fwd_const_floats;
@@ -866,6 +899,7 @@ hipError_t lsnf_launch_forward3p(const LsnfGeo& g, const float* plan, int first_
       a.stamps = g_lsnf_stamps; }
 #endif
     return B > 128 * 256 ? launch_fwd3p_w<2, 8>(a, stream) : launch_fwd3p_w<2, 4>(a, stream);
+#endif
 }
 
 // the 16x16x32 form (lsnf_fwd3q_kernel): the default throughput forward of LSNF_MATH_BF16X3 for calls it covers (nz in 66..128,

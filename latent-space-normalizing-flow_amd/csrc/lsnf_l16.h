@@ -70,6 +70,18 @@ __device__ __forceinline__ void issue_kib(const float* __restrict__ gsrc, float*
         }
     }
 }
+// one 1 KiB piece (piece s of this wave: segment s * NW + wave) of the same transfer -- for kernels that spread a buffer's
+// pieces over the steps of the phase before instead of issuing them in one burst behind the barrier
+template <int NW>
+__device__ __forceinline__ void issue_piece(const float* __restrict__ gsrc, float* lbuf, int s, int wave, int lane) {
+    const int seg = s * NW + wave;
+    const char* sb = reinterpret_cast<const char*>(gsrc) + (size_t)seg * 1024u;
+    const unsigned m0v = (unsigned)(size_t)((LSNF_AS3 char*)lbuf) + (unsigned)seg * 1024u;
+    const unsigned lane_off = (unsigned)lane * 16u;
+    unsigned keep_m0;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep_m0) : "v"(lane_off), "s"(sb), "s"(m0v) : "memory");
+}
 template <int NW>
 struct Pipe3 {
     float* buf0; int slot, cur, wave, lane;

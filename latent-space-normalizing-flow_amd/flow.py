@@ -198,14 +198,16 @@ def set_small_batch_max(rows: int) -> int:
     return _lib.load().lsnf_set_small_batch_max(int(rows))
 
 
-MATH_FP32, MATH_BF16X3, MATH_BF16X3_32, MATH_FP16X2, MATH_BF16X3_PIPE, MATH_BF16X3_PHASED = 0, 1, 2, 3, 4, 5
+MATH_FP32, MATH_BF16X3, MATH_FP16X2, MATH_BF16X3_PHASED = 0, 1, 3, 5
+# research builds of the library only (make EXTRA=-DLSNF_EXPERIMENTAL_KERNELS; refused by the shipped one): the bf16x3 scheme on
+# v_mfma_f32_32x32x16_bf16, phase-separated / software-pipelined -- both measured slower (profiles/HISTORY.md); used by tools/
+_MATH_X_BF16X3_32, _MATH_X_BF16X3_PIPE = 2, 4
 
 
 def set_math_mode(mode: int) -> int:
     """Arithmetic of the GEMMs (include/lsnf_flow.h): MATH_BF16X3 (default: error-free three-way bf16 split, 24 operand
     bits, six bf16 MFMAs per product; 16x16x32 MFMA, the throughput forward software-pipelined where it applies),
-    MATH_BF16X3_PHASED (the same without the pipelined forward), MATH_FP32 (fp32 MFMA), MATH_BF16X3_32 / MATH_BF16X3_PIPE (the
-    bf16x3 scheme on the 32x32x16 MFMA, phase-separated / software-pipelined: kept for comparison) or MATH_FP16X2
+    MATH_BF16X3_PHASED (the same without the pipelined forward), MATH_FP32 (fp32 MFMA) or MATH_FP16X2
     (opt-in, NARROWER than fp32: two-term fp16 split, three fp16 MFMAs per product, range-guarded by a bf16x3 fix-up pass).
     Returns the previous mode (mode < 0: query)."""
     return _lib.load().lsnf_set_math_mode(int(mode))

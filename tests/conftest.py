@@ -46,19 +46,16 @@ def gpu_device():
 
 
 @pytest.fixture(params=["latency-kernels", "latency-kernels-bf16x3", "throughput-kernels", "throughput-kernels-bf16x3",
-                        "throughput-kernels-bf16x3_phased", "throughput-kernels-bf16x3_32", "throughput-kernels-bf16x3_pipe",
-                        "throughput-kernels-fp16x2"])
+                        "throughput-kernels-bf16x3_phased", "throughput-kernels-fp16x2"])
 def kernels(request):
     """Every parity test runs on both kernel families (normally selected by batch size, lsnf_set_small_batch_max) and,
     for the throughput family, with both arithmetic modes of the forward's GEMMs (lsnf_set_math_mode: fp32 MFMA, or
-    the error-free three-way bf16 split on the bf16 matrix pipe -- software-pipelined (default) or phase-separated, in its
-    two MFMA shapes -- or the two-way fp16 split)."""
+    the error-free three-way bf16 split on the bf16 matrix pipe -- software-pipelined (default) or phase-separated -- or
+    the two-way fp16 split)."""
     import lsnf_amd
     prev = lsnf_amd.flow.set_small_batch_max(1 << 30 if request.param.startswith("latency-kernels") else 0)
     prev_math = lsnf_amd.flow.set_math_mode(lsnf_amd.flow.MATH_BF16X3 if request.param.endswith("bf16x3")
                                             else lsnf_amd.flow.MATH_BF16X3_PHASED if request.param.endswith("bf16x3_phased")
-                                            else lsnf_amd.flow.MATH_BF16X3_32 if request.param.endswith("bf16x3_32")
-                                            else lsnf_amd.flow.MATH_BF16X3_PIPE if request.param.endswith("bf16x3_pipe")
                                             else lsnf_amd.flow.MATH_FP16X2 if request.param.endswith("fp16x2")
                                             else lsnf_amd.flow.MATH_FP32)
     yield request.param

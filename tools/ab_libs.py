@@ -24,7 +24,7 @@ def t_us(fn, n=400):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 res = []
-for name, mode in (("fwd3b", getattr(F, "MATH_BF16X3_PHASED", F.MATH_BF16X3)), ("fwd3p", F.MATH_BF16X3_PIPE), ("fwd3q", F.MATH_BF16X3)):
+for name, mode in (("fwd3b", getattr(F, "MATH_BF16X3_PHASED", F.MATH_BF16X3)), ("fwd3p", F._MATH_X_BF16X3_PIPE), ("fwd3q", F.MATH_BF16X3)):
     F.set_math_mode(mode)
     res.append(f"{name} {t_us(lambda: lsnf_amd.forward(plan, z, out=outs)):.2f}")
 F.set_math_mode(F.MATH_BF16X3)

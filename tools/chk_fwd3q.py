@@ -13,8 +13,19 @@ F = lsnf_amd.flow
 w = bench.synth_weights(1)
 plan = lsnf_amd.prepare([t.to(dev) for t in w], bench.NZ, bench.WIDTH, bench.DEPTH)
 F.set_small_batch_max(0)
-KERNELS = {"fwd3b (16x16x32, phases)": F.MATH_BF16X3_PHASED, "fwd3p (32x32x16, pipelined)": F.MATH_BF16X3_PIPE,
+KERNELS = {"fwd3b (16x16x32, phases)": F.MATH_BF16X3_PHASED, "fwd3p (32x32x16, pipelined)": F._MATH_X_BF16X3_PIPE,
            "fwd3q (16x16x32, pipelined)": F.MATH_BF16X3, "fp32 MFMA": F.MATH_FP32}
+
+
+def accepted(mode):          # (the 32x32x16 kernels exist in research builds only: make EXTRA=-DLSNF_EXPERIMENTAL_KERNELS)
+    prev = F.set_math_mode(-1)
+    F.set_math_mode(mode)
+    ok = F.set_math_mode(-1) == mode
+    F.set_math_mode(prev)
+    return ok
+
+
+KERNELS = {k: v for k, v in KERNELS.items() if accepted(v)}
 
 
 def select(name):

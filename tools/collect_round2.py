@@ -4,7 +4,8 @@ secondary roofline table.   python tools/collect_round2.py [tag]"""
 import csv, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-R, P = os.path.join(ROOT, "gpurun_out", "round2"), os.path.join(ROOT, "profiles")
+src = sys.argv[2] if len(sys.argv) > 2 else "round2"          # gpurun_out/<src>: round2 (tools/round2_measure.sh), round3 (tools/round3_measure.sh)
+R, P = os.path.join(ROOT, "gpurun_out", src), os.path.join(ROOT, "profiles")
 last = lambda f: open(f).read().strip().splitlines()[-1] + "\n"
 for name in ("bench", "bench_fp32", "bench_fp16x2", "bench_driver_args"):
     open(os.path.join(P, f"{tag}_{name}.json"), "w").write(last(os.path.join(R, f"{name}.json")))
@@ -38,6 +39,14 @@ out["note"] = ("per-dispatch durations from rocprofv3 --kernel-trace of `python3
 json.dump(out, open(os.path.join(P, f"{tag}_kernel_only_from_trace.json"), "w"), indent=1)
 subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_traffic.py"), os.path.join(R, "pmc"), "bf16x3"], cwd=ROOT, check=True)
 subprocess.run([sys.executable, os.path.join(ROOT, "tools", "secondary_roofline.py"), R, tag], cwd=ROOT, check=True)
+for n in (8, 4, 2):                                            # round 3: one GPU's shard of an N-GPU step
+    f = os.path.join(R, f"shard_of_{n}.json")
+    if os.path.exists(f):
+        open(os.path.join(P, f"{tag}_shard_of_{n}.json"), "w").write(last(f))
+if os.path.exists(os.path.join(R, "shard_times.txt")):
+    shutil.copy(os.path.join(R, "shard_times.txt"), os.path.join(P, f"{tag}_shard_times.txt"))
+if os.path.exists(os.path.join(R, "prof_shard8", "shard8_kernel_stats.csv")):
+    shutil.copy(os.path.join(R, "prof_shard8", "shard8_kernel_stats.csv"), os.path.join(P, f"{tag}_shard_of_8_kernel_stats.csv"))
 b = json.loads(last(os.path.join(R, "bench.json")))
 print(tag, "value %.4g" % b["value"], "ms/step %.4f" % b["ms_per_step"], "kernel_ms %.4f" % b["roofline"]["kernel_ms"], "frac %.4f" % b["roofline"]["frac"],
       "| trace", {k: round(v["kernel_only_loop_last_200_avg_us"], 1) for k, v in out.items() if k != "note"})

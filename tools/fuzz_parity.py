@@ -63,7 +63,7 @@ def run(n_cases, seed, batches=BATCHES):
                 continue
             zd, od = z.to(dev), obj0.to(dev)
             flow.set_small_batch_max(small_max)
-            for mode in (flow.MATH_FP32, flow.MATH_BF16X3, flow.MATH_BF16X3_PHASED, flow.MATH_BF16X3_32, flow.MATH_BF16X3_PIPE, flow.MATH_FP16X2):
+            for mode in (flow.MATH_FP32, flow.MATH_BF16X3, flow.MATH_BF16X3_PHASED, flow.MATH_FP16X2):
                 flow.set_math_mode(mode)
                 tag = f"case{case} nz={nz} w={width} d={depth} B={B} small_max={small_max} mode={mode}"
                 for stash in (False, True):

@@ -13,7 +13,7 @@ z = torch.randn(B, nz, generator=torch.Generator().manual_seed(1))
 _, _, ll64 = O.flow_log_prob(O.to_dtype(p, torch.float64), z[:8192].double())
 zd = z.to(dev)
 for _ in range(300): flow.forward(plan, zd)
-for name, mode in (("fp32", flow.MATH_FP32), ("bf16x3", flow.MATH_BF16X3), ("bf16x3_32", flow.MATH_BF16X3_32), ("fp16x2", flow.MATH_FP16X2)):
+for name, mode in (("fp32", flow.MATH_FP32), ("bf16x3", flow.MATH_BF16X3), ("bf16x3_32", flow._MATH_X_BF16X3_32), ("fp16x2", flow.MATH_FP16X2)):
     flow.set_math_mode(mode)
     for _ in range(200): out = flow.forward(plan, zd)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

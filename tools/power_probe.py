@@ -27,8 +27,8 @@ def t_us(z, mode):
 zr = torch.randn(65536, bench.NZ, generator=torch.Generator().manual_seed(1234)).to(dev)
 zz = torch.zeros_like(zr)
 F = lsnf_amd.flow
-for name, mode in (("lsnf_fwd3q_kernel (16x16x32, pipelined)", F.MATH_BF16X3), ("lsnf_fwd3p_kernel (32x32x16, pipelined)", F.MATH_BF16X3_PIPE),
-                   ("lsnf_fwd3b_kernel (16x16x32, phases)", F.MATH_BF16X3_PHASED), ("lsnf_fwd3_kernel (32x32x16, phases)", F.MATH_BF16X3_32),
+for name, mode in (("lsnf_fwd3q_kernel (16x16x32, pipelined)", F.MATH_BF16X3), ("lsnf_fwd3p_kernel (32x32x16, pipelined)", F._MATH_X_BF16X3_PIPE),
+                   ("lsnf_fwd3b_kernel (16x16x32, phases)", F.MATH_BF16X3_PHASED), ("lsnf_fwd3_kernel (32x32x16, phases)", F._MATH_X_BF16X3_32),
                    ("lsnf_fwd2h_kernel (fp16x2)", F.MATH_FP16X2), ("lsnf_fwd_kernel (fp32 MFMA)", F.MATH_FP32)):
     a, b = t_us(zr, mode), t_us(zz, mode)
     print(f"{name:44s} random z {a:7.2f} us   zero z {b:7.2f} us   ratio {a / b:.3f}", flush=True)

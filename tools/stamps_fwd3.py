@@ -12,7 +12,7 @@ out = (torch.empty_like(z), torch.empty(z.shape[0], device=dev), torch.empty(z.s
 lib = lsnf_amd.load_library()
 lib.lsnf_debug_stamps.restype = ctypes.c_void_p
 hip = ctypes.CDLL("libamdhip64.so")
-for mode, name in ((lsnf_amd.flow.MATH_BF16X3, "bf16x3 16x16x32 (lsnf_fwd3b_kernel)"), (lsnf_amd.flow.MATH_BF16X3_32, "bf16x3 32x32x16 (lsnf_fwd3_kernel)"),
+for mode, name in ((lsnf_amd.flow.MATH_BF16X3, "bf16x3 16x16x32 (lsnf_fwd3b_kernel)"), (lsnf_amd.flow._MATH_X_BF16X3_32, "bf16x3 32x32x16 (lsnf_fwd3_kernel)"),
                    (lsnf_amd.flow.MATH_FP32, "fp32 MFMA (lsnf_fwd_kernel)")):
     lsnf_amd.flow.set_math_mode(mode)
     t0 = time.perf_counter()

@@ -8,13 +8,14 @@ import numpy as np, torch
 import bench, lsnf_amd
 dev = torch.device("cuda:0")
 plan = lsnf_amd.prepare([t.to(dev) for t in bench.synth_weights(1)], bench.NZ, bench.WIDTH, bench.DEPTH)
-z = torch.randn(bench.B_GLOBAL, bench.NZ, generator=torch.Generator().manual_seed(1234)).to(dev)
+BROWS = int(sys.argv[2]) if len(sys.argv) > 2 else bench.B_GLOBAL
+z = torch.randn(BROWS, bench.NZ, generator=torch.Generator().manual_seed(1234)).to(dev)
 out = (torch.empty_like(z), torch.empty(z.shape[0], device=dev), torch.empty(z.shape[0], device=dev))
 lib = lsnf_amd.load_library()
 lib.lsnf_debug_stamps.restype = ctypes.c_void_p
 hip = ctypes.CDLL("libamdhip64.so")
-which = sys.argv[1] if len(sys.argv) > 1 else "p"          # p: lsnf_fwd3p_kernel (32x32x16), q: lsnf_fwd3q_kernel (16x16x32)
-lsnf_amd.flow.set_math_mode(lsnf_amd.flow.MATH_BF16X3 if which == "q" else lsnf_amd.flow.MATH_BF16X3_PIPE)
+which = sys.argv[1] if len(sys.argv) > 1 else "q"          # p: lsnf_fwd3p_kernel (32x32x16), q: lsnf_fwd3q_kernel (16x16x32)
+lsnf_amd.flow.set_math_mode(lsnf_amd.flow.MATH_BF16X3 if which == "q" else lsnf_amd.flow._MATH_X_BF16X3_PIPE)
 lsnf_amd.flow.set_small_batch_max(0)
 t0 = time.perf_counter(); n = 0
 while time.perf_counter() - t0 < 2.5:
