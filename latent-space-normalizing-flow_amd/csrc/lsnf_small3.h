@@ -104,18 +104,21 @@ __device__ __forceinline__ const bf16x8* unit_ptr(const float* stage, int nt, in
 //    block b+1's S1, whose k-tiles 0, 1 only read the v1 half of the input.
 // K0..K1 = the k-tiles of this call (a stage can be cut in two calls around a barrier: the refill rule carries over).
 struct NoEpi { __device__ __forceinline__ void operator()(int) const {} };
-template <int KT, int K0, int K1, int ST, int NU, int EV, int CN, int FV, class Epi, class Carry, class Fill>
+// KS: k-tiles >= KS of the input live at in_hi (k-tile kt at in_hi + (kt - KS) tiles; same sample-tile stride) -- the backward's
+// g_v, whose second half is double-buffered.
+template <int KT, int K0, int K1, int ST, int NU, int EV, int CN, int FV, int KS = KT, class Epi, class Carry, class Fill>
 __device__ __forceinline__ void units_mma_st(f32x4* acc0, f32x4* acc1, UFrags<KT>& f0, UFrags<KT>& f1,
                                              const bf16x8* r0, const bf16x8* r1, const float* in_tiles, int st_stride, int lane,
-                                             Epi&& epi, Carry&& carry, Fill&& fill) {
+                                             Epi&& epi, Carry&& carry, Fill&& fill, const float* in_hi = nullptr) {
     constexpr int STEPS = (K1 - K0) * ST, NM = 6 * NU;
+    auto tile_at = [&](int kt, int st) { return (kt < KS ? in_tiles + kt * S3_BTILE_FLOATS : in_hi + (kt - KS) * S3_BTILE_FLOATS) + st * st_stride; };
     __builtin_amdgcn_sched_barrier(0);
-    BOp b = load_btile(in_tiles + K0 * S3_BTILE_FLOATS, lane);
+    BOp b = load_btile(tile_at(K0, 0), lane);
     __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
     lsnf_static_for<STEPS>([&](auto ic) {
         constexpr int i = decltype(ic)::value, kt = K0 + i / ST, st = i % ST;
         BOp nb = b;
-        if constexpr (i + 1 < STEPS) nb = load_btile(in_tiles + ((i + 1) % ST) * st_stride + (K0 + (i + 1) / ST) * S3_BTILE_FLOATS, lane);
+        if constexpr (i + 1 < STEPS) nb = load_btile(tile_at(K0 + (i + 1) / ST, (i + 1) % ST), lane);
         constexpr bool with_epi = EV > 0 && K1 == KT && kt == KT - 1 && st >= 1;
         constexpr bool with_fill = FV > 0 && kt == K0;
         if constexpr (with_epi) epi(st - 1);
@@ -206,7 +209,24 @@ __device__ __forceinline__ void store_plain_half(const f32x4& x, float* __restri
             if (c0 + j < ld) zr[c0 + j] = x[j];
     }
 }
-// sum over the 4 lane groups of a per-sample value
-__device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+// lane exchanges on the vector ALU (gfx950: v_permlane16_swap / v_permlane32_swap; __shfl_xor goes through the LDS crossbar and
+// costs a ~100-cycle round trip).  swap(v, v) returns the pair (r0, r1) in which every lane holds its own value in one and
+// its partner's (lane ^ 16 resp. lane ^ 32) in the other: own (+ or |) partner = r0 (+ or |) r1 on every lane.
+__device__ __forceinline__ float pair_add16(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ float pair_add32(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ unsigned pair_or32(unsigned u) {
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return (unsigned)r[0] | (unsigned)r[1];
+}
+// sum over the 4 lane groups of a per-sample value (lanes n, n + 16, n + 32, n + 48)
+__device__ __forceinline__ float group_sum(float v) { return pair_add32(pair_add16(v)); }
 
 }  // namespace

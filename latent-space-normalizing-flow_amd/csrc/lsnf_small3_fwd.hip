@@ -31,7 +31,7 @@ struct Small3Cfg : LsnfStackCfg<HT_, WT_> {
     static constexpr int NU2 = (2 * WT_ + 3) / 4;              // hidden half-units per wave
 };
 // LDS map (floats) of a workgroup that owns ST sample tiles of 16 rows: X ping-pong (2 x ST x NZT B-tiles), H1, H2
-// (ST x WT B-tiles each), mask words (ST x 2 x WT x 32), reductions (ST x 4 waves x 16 x 2), then the constant blocks
+// (ST x WT B-tiles each), reductions (ST x 4 waves x 16 x 2), then the constant blocks
 template <class C, int ST>
 struct Small3Lds {
     static constexpr int XT = C::NZT * S3_BTILE_FLOATS;        // one sample tile's block input
@@ -39,8 +39,7 @@ struct Small3Lds {
     static constexpr int L_X = 0;
     static constexpr int L_H1 = L_X + 2 * ST * XT;
     static constexpr int L_H2 = L_H1 + ST * HL;
-    static constexpr int L_MASK = L_H2 + ST * HL;
-    static constexpr int L_RED = L_MASK + ST * 2 * C::WT * 32;
+    static constexpr int L_RED = L_H2 + ST * HL;
     static constexpr int L_CONST = L_RED + ST * 4 * 16 * 2;
 };
 
@@ -64,6 +63,22 @@ struct Small3Args {
 #define S3_STAMP(i, INSN) do {} while (0)
 #endif
 
+// ReLU mask of one half-unit (nt, ft) of a hidden layer into the stash (lsnf_layout.h LsnfActLayout: per 32-sample tile and hidden
+// tile one 32-bit word per stash lane, bit 4*(2*ft + (g >> 1)) + r = h[r] > 0): the two lane groups g >> 1 meet in one
+// v_permlane32_swap, and what a wave then holds is exactly BYTE ft of the word -- stored as a byte by lanes 0..31; no LDS staging, no atomics
+// (the ft = 1 wave also clears the unused upper half).
+__device__ __forceinline__ void stash_relu_mask(float* act_tile, size_t mask_off, int t, int lane32, int ft, const f32x4& h, int lane) {
+    unsigned c = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c |= (h[r] > 0.0f ? 1u : 0u) << (4 * (lane >> 5) + r);
+    c = pair_or32(c);
+    if (lane < 32) {
+        unsigned char* w = reinterpret_cast<unsigned char*>(reinterpret_cast<unsigned*>(act_tile + mask_off) + t * 64 + lane32);
+        w[ft] = (unsigned char)c;
+        if (ft) *reinterpret_cast<unsigned short*>(w + 2) = (unsigned short)0;
+    }
+}
+
 // ST = sample tiles (of 16 rows) per workgroup.  ST = 1 is the latency form (B = 100: 7 workgroups).  ST = 2 / 4 are the
 // SHARD-SIZE forms (strong scaling of the 65 536-row evaluation over 8 / 4 GPUs leaves 8 192 / 16 384 rows per GPU): a
 // workgroup of 32 / 64 rows streams the same 192 KiB of weights per block as a 16-row one -- every fetched fragment triple
@@ -81,7 +96,6 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_fwd_kernel(const Small3Arg
     float* XB = smem + L::L_X;                                           // [ping-pong][st][NZT] B-tiles
     float* H1B = smem + L::L_H1;                                         // [st][WT]
     float* H2B = smem + L::L_H2;
-    unsigned* MASK = reinterpret_cast<unsigned*>(smem + L::L_MASK);      // [st][h1 | h2][WT][32]
     float* RED = smem + L::L_RED;
     float* cst = smem + L::L_CONST;
     const int tid = threadIdx.x;
@@ -151,7 +165,6 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_fwd_kernel(const Small3Arg
     }
     __builtin_amdgcn_sched_barrier(0);
     S3_STAMP(4, "s_memtime");
-    if (EXTRAS) for (int i = tid; i < ST * 2 * WT * 32; i += 256) MASK[i] = 0u;
     // the first-half unit goes to LDS now; the second-half unit stays in registers: it is the "v2" of a virtual block -1 whose
     // coupling is the identity (below), run under the first block's S1 like every other block's
 #pragma unroll
@@ -179,13 +192,13 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_fwd_kernel(const Small3Arg
     const LsnfDumpLayout dl = lsnf_dump_layout(a.B, a.nz, a.width);
     const bool w4 = (a.width & 3) == 0;
     // stash addressing: 16-row tile q = blockIdx.x * ST + st is half (q & 1) of the 32-sample stash tile q >> 1
-    size_t wtile[ST]; int sth[ST], lane32[ST]; bool tile_ok[ST];
+    size_t wtile[ST]; int lane32[ST]; bool tile_ok[ST];
 #pragma unroll
     for (int st = 0; st < ST; ++st) {
         const size_t q = (size_t)blockIdx.x * ST + st;
-        wtile[st] = q >> 1; sth[st] = (int)(q & 1);
+        wtile[st] = q >> 1;
         tile_ok[st] = (long)q * S3_SAMPLES < (long)a.B;                   // (a 16-row tile past the batch has no stash tile: nothing of it is stored)
-        lane32[st] = 16 * sth[st] + n + 32 * (g & 1);                     // stash lane of (sample, feature-group parity)
+        lane32[st] = 16 * (int)(q & 1) + n + 32 * (g & 1);                // stash lane of (sample, feature-group parity)
     }
     // (the row loads above are older than every weight load: the split above waited for them and, in order, for the constants' DMA)
     S3_STAMP(5, "s_memtime");
@@ -226,8 +239,13 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_fwd_kernel(const Small3Arg
                 }
                 if (a.z_saved != nullptr && pb + 1 < a.n_blocks && live[st]) {
                     float* zr = a.z_saved + ((size_t)pb * a.B + sample[st]) * a.nz;
-                    store_row_half<HT>(nt1, ft1, v1[st], zr, a.half, g, a.vec4);
-                    store_row_half<HT>(HT + nt1, ft1, y2[st], zr, a.half, g, a.vec4);
+                    if (a.vec4 == 4) {
+                        store_row_half<HT>(nt1, ft1, v1[st], zr, a.half, g, 4);
+                        store_row_half<HT>(HT + nt1, ft1, y2[st], zr, a.half, g, 4);
+                    } else {
+                        store_row_half<HT>(nt1, ft1, v1[st], zr, a.half, g, a.vec4);
+                        store_row_half<HT>(HT + nt1, ft1, y2[st], zr, a.half, g, a.vec4);
+                    }
                 }
             }
         }
@@ -303,12 +321,7 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_fwd_kernel(const Small3Arg
 #pragma unroll
                 for (int st = 0; st < ST; ++st) {
                     if (hd[st]) store_plain_half(h[st], hd[st] + dl.off_h1, a.width, nt, ft, g, w4);
-                    if (act[st]) {
-                        unsigned c = 0;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) c |= (h[st][r] > 0.0f ? 1u : 0u) << (4 * (2 * ft + (g >> 1)) + r);
-                        atomicOr(&MASK[(st * 2 * WT + nt) * 32 + n + 16 * (g & 1)], c);
-                    }
+                    if (act[st]) stash_relu_mask(act[st], al.mask_off, nt, lane32[st], ft, h[st], lane);
                 }
             }
         }
@@ -316,14 +329,6 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_fwd_kernel(const Small3Arg
         __syncthreads();
         if (blk == 1) S3_STAMP(15, "s_memtime");
         // ---- S3: h2 = relu(actnorm(h1 @ W2)) (model.py:326-328,308) ----
-        if (EXTRAS && a.act_saved) {     // h1's mask words are complete: out to the stash, slots re-armed
-            for (int i = tid; i < ST * WT * 32; i += 256) {
-                const int st = i / (WT * 32), t = (i / 32) % WT, j = i & 31;   // j = n + 16*(g&1) of the word
-                unsigned* slot = &MASK[(st * 2 * WT + t) * 32 + j];
-                if (act[st]) reinterpret_cast<unsigned*>(act[st] + al.mask_off)[t * 64 + 16 * sth[st] + (j & 15) + 32 * (j >> 4)] = *slot;
-                *slot = 0u;
-            }
-        }
 #pragma unroll
         for (int i = 0; i < NU2; ++i) {
             const int nt = hw[i] >> 1, ft = hw[i] & 1;
@@ -351,12 +356,7 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_fwd_kernel(const Small3Arg
 #pragma unroll
                 for (int st = 0; st < ST; ++st) {
                     if (hd[st]) store_plain_half(h[st], hd[st] + dl.off_h2, a.width, nt, ft, g, w4);
-                    if (act[st]) {
-                        unsigned c = 0;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) c |= (h[st][r] > 0.0f ? 1u : 0u) << (4 * (2 * ft + (g >> 1)) + r);
-                        atomicOr(&MASK[(st * 2 * WT + WT + nt) * 32 + n + 16 * (g & 1)], c);
-                    }
+                    if (act[st]) stash_relu_mask(act[st], al.mask_off, WT + nt, lane32[st], ft, h[st], lane);
                 }
             }
         }
@@ -364,14 +364,6 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_fwd_kernel(const Small3Arg
         __syncthreads();
         if (blk == 1) S3_STAMP(17, "s_memtime");
         // ---- S4: shift t / pre-sigmoid p (model.py:347-349,411-413); the coupling itself (:414-418) rides under the next S1 ----
-        if (EXTRAS && a.act_saved) {
-            for (int i = tid; i < ST * WT * 32; i += 256) {
-                const int st = i / (WT * 32), t = (i / 32) % WT, j = i & 31;
-                unsigned* slot = &MASK[(st * 2 * WT + WT + t) * 32 + j];
-                if (act[st]) reinterpret_cast<unsigned*>(act[st] + al.mask_off)[(WT + t) * 64 + 16 * sth[st] + (j & 15) + 32 * (j >> 4)] = *slot;
-                *slot = 0u;
-            }
-        }
         {
             const f32x4 bt = unit_bias(cb + 32 * (C::P1 + C::P2 + C::P3 + nt1), ft1, g);
             const f32x4 bp = unit_bias(cb + 32 * (C::P1 + C::P2 + C::P3 + HT + nt1), ft1, g);

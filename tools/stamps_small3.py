@@ -15,10 +15,13 @@ lib = lsnf_amd.load_library()
 lib.lsnf_debug_stamps.restype = ctypes.c_void_p
 hip = ctypes.CDLL("libamdhip64.so")
 lsnf_amd.flow.set_small_batch_max(1 << 30)
+EXTRAS = len(sys.argv) > 2 and sys.argv[2] == "extras"          # the stash-writing forward (block outputs + activation stash)
+act = lsnf_amd.flow.new_act_saved(plan, B, dev) if EXTRAS else None
+saved = torch.empty(bench.DEPTH - 1, B, bench.NZ, device=dev) if EXTRAS else None
 t0 = time.perf_counter(); n = 0
 while time.perf_counter() - t0 < 1.5:
     for _ in range(200):
-        lsnf_amd.forward(plan, z, out=out)
+        lsnf_amd.forward(plan, z, out=out, act_saved=act, z_saved_out=saved)
     torch.cuda.synchronize(); n += 200
 buf = (ctypes.c_ulonglong * (2048 * 64))()
 hip.hipMemcpy(buf, ctypes.c_void_p(lib.lsnf_debug_stamps()), ctypes.c_size_t(2048 * 64 * 8), 2)
@@ -29,7 +32,7 @@ s = s[:nw]
 cyc = (s[:, 41] - s[:, 0]).astype(np.float64); rt = (s[:, 51] - s[:, 50]).astype(np.float64)
 ok = rt > 0
 med = lambda a: np.median(a[ok])
-print(f"lsnf_small3_fwd_kernel ST={st or 'auto'} B={B} after {n} launches: in-kernel clock {med(cyc / np.maximum(rt, 1)) * 0.1:.3f} GHz; "
+print(f"lsnf_small3_fwd_kernel{' (EXTRAS)' if EXTRAS else ''} ST={st or 'auto'} B={B} after {n} launches: in-kernel clock {med(cyc / np.maximum(rt, 1)) * 0.1:.3f} GHz; "
       f"wave lifetime {med(rt) / 100:.2f} us = {med(cyc):.0f} cycles")
 print(f"  prologue (weight requests, row loads, split, barrier) {med(s[:, 1] - s[:, 0]):8.0f}")
 for nm, (i, j) in [("    consts DMA issued", (0, 2)), ("    row loads issued", (2, 3)), ("    weight loads issued", (3, 4)), ("    rows waited for, split, LDS stores", (4, 5)), ("    barrier", (5, 1))]:
