@@ -30,14 +30,15 @@ struct Small3Cfg : LsnfStackCfg<HT_, WT_> {
     static constexpr int CONST_FLOATS = S::FWD_CONST;
     static constexpr int NU2 = (2 * WT_ + 3) / 4;              // hidden half-units per wave
 };
-// LDS map (floats) of a workgroup that owns ST sample tiles of 16 rows: X ping-pong (2 x ST x NZT B-tiles), H1, H2
+// LDS map (floats) of a workgroup that owns ST sample tiles of 16 rows: X (ST x NZT B-tiles; ONE buffer: with the coupling of
+// block b deferred into block b+1's first S1 half, every tile is rewritten only after a barrier behind its last reader), H1, H2
 // (ST x WT B-tiles each), reductions (ST x 4 waves x 16 x 2), then the constant blocks
 template <class C, int ST>
 struct Small3Lds {
     static constexpr int XT = C::NZT * S3_BTILE_FLOATS;        // one sample tile's block input
     static constexpr int HL = C::WT * S3_BTILE_FLOATS;         // one sample tile's hidden layer
     static constexpr int L_X = 0;
-    static constexpr int L_H1 = L_X + 2 * ST * XT;
+    static constexpr int L_H1 = L_X + ST * XT;
     static constexpr int L_H2 = L_H1 + ST * HL;
     static constexpr int L_RED = L_H2 + ST * HL;
     static constexpr int L_CONST = L_RED + ST * 4 * 16 * 2;
@@ -88,12 +89,19 @@ __device__ __forceinline__ void stash_relu_mask(float* act_tile, size_t mask_off
 // EXTRAS = the call keeps something for a backward pass (block outputs z_saved, the activation stash act_saved, h1 / h2 for
 // the parameter gradients): the plain log-prob evaluation is compiled without those stores and their branches, so that each
 // stage is one scheduling region.
+// (Tried: two workgroups per CU -- __launch_bounds__(256, 2), 512 32-row workgroups for 16 384 rows, so that a second wave on the
+// SIMD fills the first one's bubbles.  68 B/lane of scratch at 256 registers, and the two workgroups stream the weights twice
+// through the CU's one vector-memory path: 35.1 us at 16 384 rows against 31.9 for lsnf_fwd3q_kernel, 22.4 instead of 20.1 at
+// 8 192.  LSNF_SMALL3_WAVES2=1 rebuilds that form.)
+#ifndef LSNF_SMALL3_WAVES2
+#define LSNF_SMALL3_WAVES2 0
+#endif
 template <class C, int ST, bool EXTRAS>
-__global__ __launch_bounds__(256, 1) void lsnf_small3_fwd_kernel(const Small3Args a) {
+__global__ __launch_bounds__(256, (LSNF_SMALL3_WAVES2 && ST <= 2 && C::WT <= 2 && !EXTRAS) ? 2 : 1) void lsnf_small3_fwd_kernel(const Small3Args a) {
     constexpr int HT = C::HT, WT = C::WT, NZT = C::NZT, NU2 = C::NU2;
     using L = Small3Lds<C, ST>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* XB = smem + L::L_X;                                           // [ping-pong][st][NZT] B-tiles
+    float* XB = smem + L::L_X;                                           // [st][NZT] B-tiles
     float* H1B = smem + L::L_H1;                                         // [st][WT]
     float* H2B = smem + L::L_H2;
     float* RED = smem + L::L_RED;
@@ -255,8 +263,11 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_fwd_kernel(const Small3Arg
         const float* gblk = a.panels3b + (size_t)blk * C::BLOCK3;
         const bool more = blk + 1 < a.n_blocks;
         const float* gnext = more ? gblk + C::BLOCK3 : gblk;             // last block re-fetches its own panels: no loads under a branch
-        float* Xc = XB + (blk & 1) * ST * L::XT;
-        float* Xn = XB + ((blk + 1) & 1) * ST * L::XT;
+        // Block input tiles: first half = v1 of the previous block (written by its second S1 half, read by its S2 and by this
+        // block's first S1 half), second half = y2 of the previous block (written under this block's first S1 half, read by its
+        // second).  One buffer: a writer is always at least one barrier behind the tile's last reader.
+        float* Xc = XB;
+        float* Xn = XB;
         float* act[ST]; float* hd[ST];
 #pragma unroll
         for (int st = 0; st < ST; ++st) {
@@ -380,9 +391,9 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_fwd_kernel(const Small3Arg
         // (no barrier here: the next block's first S1 half reads tiles that were published before this block's S2)
         if (blk == 1) S3_STAMP(20, "s_memtime");
     }
-    // the last block's coupling (no S1 follows); its operand tiles are not needed: store_half targets a dead buffer
+    // the last block's coupling (no S1 follows); its operand tiles are not needed (nobody reads X any more)
 #pragma unroll
-    for (int st = 0; st < ST; ++st) couple(st, XB + (a.n_blocks & 1) * ST * L::XT);
+    for (int st = 0; st < ST; ++st) couple(st, XB);
     keep_block(a.n_blocks - 1);
     S3_STAMP(40, "s_memtime");
 
@@ -530,7 +541,7 @@ __global__ __launch_bounds__(256, 1) void lsnf_small3_restash_kernel(const Resta
 
 template <class C, int ST>
 hipError_t launch_small3_fwd_st(const Small3Args& a, hipStream_t stream) {
-    if constexpr ((size_t)(Small3Lds<C, ST>::L_CONST + C::CONST_FLOATS) * sizeof(float) > 160 * 1024) {
+    if constexpr ((size_t)(Small3Lds<C, ST>::L_CONST + C::CONST_FLOATS) * sizeof(float) > 160 * 1024 || (ST == 4 && C::WT > 2)) {
         return hipErrorInvalidValue;                 // (this shape cannot fit for any depth: not instantiated)
     } else {
         const size_t lds = ((size_t)Small3Lds<C, ST>::L_CONST + (size_t)a.n_blocks * C::CONST_FLOATS) * sizeof(float);
@@ -550,7 +561,9 @@ hipError_t launch_small3_fwd_st(const Small3Args& a, hipStream_t stream) {
 template <class C>
 hipError_t launch_small3_fwd(const Small3Args& a, hipStream_t stream) {
     static const char* env = getenv("LSNF_SMALL3_ST");
-    int st = env ? atoi(env) : (a.B <= 256 * 16 ? 1 : (a.B <= 256 * 32 ? 2 : 4));
+    const bool extras = a.z_saved != nullptr || a.act_saved != nullptr || a.hdump != nullptr;
+    // (the plain 32-row form runs two workgroups per CU: 512 of them cover 16 384 rows in one round)
+    int st = env ? atoi(env) : (a.B <= 256 * 16 ? 1 : ((a.B <= 256 * 32 || (LSNF_SMALL3_WAVES2 && !extras && C::WT <= 2 && a.B <= 512 * 32)) ? 2 : 4));
     hipError_t e = hipErrorInvalidValue;
     if (st >= 4) e = launch_small3_fwd_st<C, 4>(a, stream);
     if (e == hipErrorInvalidValue && st >= 2) e = launch_small3_fwd_st<C, 2>(a, stream);     // (the larger shape did not fit into LDS)
