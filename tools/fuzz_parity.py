@@ -10,7 +10,7 @@ from lsnf_amd import flow
 from oracle import flow_oracle as O, philox_oracle as PO
 
 dev = torch.device("cuda:0")
-BATCHES = [1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 255, 257, 1000, 4097, 16384, 16385, 32768, 32769]
+BATCHES = [1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 255, 257, 1000, 4097, 5003, 8193, 9001, 16384, 16385, 32768, 32769]
 fails, checks = [], 0
 
 
