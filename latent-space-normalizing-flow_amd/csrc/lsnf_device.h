@@ -222,8 +222,25 @@ __device__ __forceinline__ void lsnf_sigmoid_logsig(float p, float& sig, float& 
 #endif
 }
 
+// Lane exchanges on the vector ALU (gfx950: v_permlane16_swap / v_permlane32_swap; __shfl_xor goes through the LDS crossbar:
+// a ~100-cycle round trip).  swap(v, v) returns the pair (r0, r1) in which every lane holds its own value in one and its
+// partner's (lane ^ 16 resp. lane ^ 32) in the other: own (+ or |) partner = r0 (+ or |) r1 on every lane.
+__device__ __forceinline__ float lsnf_pair_add16(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ float lsnf_pair_add32(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ unsigned lsnf_pair_or32(unsigned u) {
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return (unsigned)r[0] | (unsigned)r[1];
+}
 // sum of a value held by lanes l and l+32 (the two feature half-groups of one sample)
-__device__ __forceinline__ float lsnf_pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ float lsnf_pair_sum(float v) { return lsnf_pair_add32(v); }
 
 // ---- latent rows <-> split-pad register tiles -------------------------------------------------
 // row: sample index (already clamped to [0,B)), tile t of the split-pad row: x[r] <- feature nat(32*t + o(r,h)).

@@ -294,7 +294,7 @@ __device__ __forceinline__ void l16_gemm_stage3(Pipe& pipe, const float* gsrc, c
 }
 
 // sum over the 4 lane groups of a per-sample value (lanes n, n+16, n+32, n+48)
-__device__ __forceinline__ float l16_group_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ float l16_group_sum(float v) { return lsnf_pair_add32(lsnf_pair_add16(v)); }
 // relu masks of one tile in the stash's (32x32-layout) word format: lanes with g < 2 end up holding the word of
 // stash lane 16*st + n + 32*g for st = 0 / 1 (see the derivation in DESIGN.md section 4)
 __device__ __forceinline__ void l16_store_masks(unsigned* words, const f32x16& a, int n, int g) {
@@ -305,7 +305,7 @@ __device__ __forceinline__ void l16_store_masks(unsigned* words, const f32x16& a
         for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
             for (int r = 0; r < 4; ++r) c |= (a[(2 * ft + st) * 4 + r] > 0.0f ? 1u : 0u) << (4 * (2 * ft + (g >> 1)) + r);
-        c |= __shfl_xor(c, 32, 64);
+        c = lsnf_pair_or32(c);
         if (g < 2) words[16 * st + n + 32 * g] = c;
     }
 }

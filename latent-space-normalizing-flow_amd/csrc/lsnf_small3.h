@@ -209,24 +209,9 @@ __device__ __forceinline__ void store_plain_half(const f32x4& x, float* __restri
             if (c0 + j < ld) zr[c0 + j] = x[j];
     }
 }
-// lane exchanges on the vector ALU (gfx950: v_permlane16_swap / v_permlane32_swap; __shfl_xor goes through the LDS crossbar and
-// costs a ~100-cycle round trip).  swap(v, v) returns the pair (r0, r1) in which every lane holds its own value in one and
-// its partner's (lane ^ 16 resp. lane ^ 32) in the other: own (+ or |) partner = r0 (+ or |) r1 on every lane.
-__device__ __forceinline__ float pair_add16(float v) {
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-}
-__device__ __forceinline__ float pair_add32(float v) {
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-}
-__device__ __forceinline__ unsigned pair_or32(unsigned u) {
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return (unsigned)r[0] | (unsigned)r[1];
-}
+// (lane exchanges on the vector ALU: lsnf_device.h lsnf_pair_add16 / lsnf_pair_add32 / lsnf_pair_or32)
+__device__ __forceinline__ unsigned pair_or32(unsigned u) { return lsnf_pair_or32(u); }
 // sum over the 4 lane groups of a per-sample value (lanes n, n + 16, n + 32, n + 48)
-__device__ __forceinline__ float group_sum(float v) { return pair_add32(pair_add16(v)); }
+__device__ __forceinline__ float group_sum(float v) { return lsnf_pair_add32(lsnf_pair_add16(v)); }
 
 }  // namespace
