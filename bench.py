@@ -257,6 +257,14 @@ def main():
     ap.add_argument("--shard-of", type=int, default=0, metavar="N",
                     help="one GPU: time the shard of an N-GPU strong-scaling job (65 536 / N rows per step, same protocol) and "
                          "print the N-GPU ceiling it implies; the full-size step is timed in the same run")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="on: replay the K timed steps (forward launches, and for N > 1 their all-reduces, all on one stream then) from "
+                         "ONE captured HIP graph instead of issuing them from Python.  With a live RCCL process group the eager step "
+                         "costs ~31-50 us of host time (forward call 11, async all-reduce 21-24; tools/host_cost_allreduce.py) against a "
+                         "~20 us shard kernel, so an N-GPU strong-scaling run issued from Python is HOST-bound; a captured graph of 20 "
+                         "steps replays at 22 us per step in the one-rank rehearsal.  auto = off: collectives inside a captured graph "
+                         "could only be rehearsed with one rank on this pool (a multi-stream capture around them crashed), so the "
+                         "default stays the eager loop that has run on every backend")
     ap.add_argument("--reps", type=int, default=0, help="repetitions of the K-step timed region (default max(5, ceil(200 / K)))")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -311,6 +319,7 @@ def main():
         return z, outs, reducers, streams
 
     reps = args.reps if args.reps > 0 else max(5, -(-200 // max(1, args.steps)))
+    graph_used = []
 
     def timed(run, steps, warmup):
         """clock ramp (untimed, not steps) + W untimed steps, then `reps` x (K timed steps); returns the list of seconds per
@@ -339,13 +348,64 @@ def main():
                 s_.wait_stream(main_stream)
         for _ in range(warmup):
             step()
+        # The K timed steps as ONE captured graph (see --graph): forward launches and all-reduces on the same streams in the same
+        # order as the eager loop; the reducers' flush + waits (what fence() does eagerly) are captured at the end.
+        graph = None
+        want = args.graph == "on"          # (auto = off: see --graph)
+        if want and dist is not None and args.backend != "nccl":
+            if rank == 0:
+                print(f"[bench] --graph: the {args.backend} backend cannot be captured (host copies): issuing the steps eagerly", file=sys.stderr)
+            want = False
+        if want:
+            fence(reducers, streams)
+            try:
+                cap = torch.cuda.Stream()
+                # (the legacy default stream cannot take part in a capture: the single-stream run is captured on `cap` itself; with
+                #  collectives in the graph everything is captured on ONE stream -- a fork / join over side streams around RCCL
+                #  collectives crashed the process in the one-rank rehearsal, tools/host_cost_allreduce.py)
+                if dist is not None:
+                    streams, reducers = [cap], reducers[:1]
+                    counter[0] = 0
+                else:
+                    streams[:] = [cap if s_ is main_stream else s_ for s_ in streams]
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(cap):
+                    with torch.cuda.graph(g, stream=cap):
+                        for s_ in streams:
+                            if s_ is not cap:
+                                s_.wait_stream(cap)
+                        for _ in range(steps):
+                            step()
+                        for red, s_ in zip(reducers, streams):
+                            with torch.cuda.stream(s_):
+                                red.finish()
+                        for s_ in streams:
+                            if s_ is not cap:
+                                cap.wait_stream(s_)
+                torch.cuda.synchronize()
+                g.replay()                                   # one untimed replay: the graph works before it is timed
+                torch.cuda.synchronize()
+                graph = g
+            except Exception as e:                           # e.g. a backend that cannot be captured (gloo's host copies)
+                if rank == 0:
+                    print(f"[bench] graph capture not available ({type(e).__name__}: {str(e)[:120]}): issuing the steps eagerly", file=sys.stderr)
+                torch.cuda.synchronize()
+                graph = None
+        graph_used.append(graph is not None)
         out = []
         for _ in range(reps):
-            fence(reducers, streams)
+            fence(reducers, streams) if graph is None else (torch.cuda.synchronize(), dist is not None and dist.barrier(), torch.cuda.synchronize())
             t0 = time.perf_counter()
-            for _ in range(steps):
-                step()
-            fence(reducers, streams)
+            if graph is None:
+                for _ in range(steps):
+                    step()
+                fence(reducers, streams)
+            else:
+                graph.replay()
+                torch.cuda.synchronize()
+                if dist is not None:
+                    dist.barrier()
+                torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
             if dist is not None:
                 t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -508,6 +568,7 @@ def main():
             "ms_per_step_single_stream_p90": head["ms_per_step_single_stream_p90"],
             "value_single_stream": head["value_single_stream"],
             "untimed_launches_before_timed_region": max(0, args.ramp) + args.warmup,
+            "steps_issued_from": "one captured HIP graph per timed region (forward launches + all-reduces)" if (graph_used and graph_used[0]) else "Python, one call per launch",
             "config": {"workload": "CIFAR-10 flow prior nz=128 f_width=64 f_depth=5 affine, forward+logdet+log-prob, "
                                    "B=65536 synthetic z per evaluation (BASELINE.json configs[2])",
                        "rows_per_gpu": head["rows_per_gpu"], "global_rows": head["global_rows_per_step"],
