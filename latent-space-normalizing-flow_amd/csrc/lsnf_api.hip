@@ -345,17 +345,23 @@ int lsnf_reverse(const float* plan, int nz, int width, int depth, int coupling, 
     const int vec4 = row_vector_width(g, {z_in, z_out});
     hipError_t e = hipErrorInvalidValue;
     if (l16_math()) {        // on the bf16 pipe: lsnf_small3_rev.hip / lsnf_rev3.hip
+        // the reverse neither writes nor reads a stash, so under the automatic threshold it takes its own crossover: the 64-row latency
+        // form is the faster one up to ~28 K rows (profiles/r03_latency_reverse.txt: 34.2 vs 57.9 us at 16 384, 67.3 vs 60.6 at 32 768)
+        int small_max = small_batch_max();
+        if (small_batch_setting() == LSNF_SMALL_BATCH_AUTO && math_mode() != LSNF_MATH_FP16X2 && small_max < 24576) small_max = 24576;
         // fp16 two-term split (lsnf_rev2h.hip) + the bf16x3 kernel behind it as the early-exit fix-up pass, as in lsnf_forward
-        if (B > small_batch_max() && math_mode() == LSNF_MATH_FP16X2 && z_in != z_out && (objective == nullptr || objective != objective_out)) {
+        if (B > small_max && math_mode() == LSNF_MATH_FP16X2 && z_in != z_out && (objective == nullptr || objective != objective_out)) {
             e = lsnf_launch_reverse2h(g, plan, B, z_in, objective, z_out, objective_out, vec4, 0, (hipStream_t)stream);
             if (e == hipSuccess)
                 e = lsnf_launch_reverse3(g, plan, B, z_in, objective, z_out, objective_out, vec4, /*fixup=*/1, (hipStream_t)stream);
         }
-        if (B > small_batch_max() && e == hipErrorInvalidValue)
+        if (B > small_max && e == hipErrorInvalidValue)
             e = lsnf_launch_reverse3(g, plan, B, z_in, objective, z_out, objective_out, vec4, /*fixup=*/0, (hipStream_t)stream);
         // (the latency form is also faster than the fp32 throughput reverse where the bf16 throughput form does not fit)
-        if (e == hipErrorInvalidValue && small_batch_max() > 0)
+        if (e == hipErrorInvalidValue && small_max > 0)
             e = lsnf_launch_small3_reverse(g, plan, B, z_in, objective, z_out, objective_out, vec4, (hipStream_t)stream);
+        if (e == hipErrorInvalidValue && B > small_batch_max() && B <= small_max)       // the latency form does not cover this stack
+            e = lsnf_launch_reverse3(g, plan, B, z_in, objective, z_out, objective_out, vec4, /*fixup=*/0, (hipStream_t)stream);
     }
     if (e == hipErrorInvalidValue)      // not taken or not covered: the fp32-MFMA kernels of the batch size's family
         e = (B <= small_batch_max())

@@ -26,9 +26,12 @@
 // sched_group_barrier (1 MFMA, V VALU); V <= 6 keeps the issue cost inside the MFMA's 32 cycles.
 //
 // Same math, same prepared weights (plan region off_f3_panels) and the same I/O contract as lsnf_fwd3_kernel; replaces
-// reference model.py:473-483 + train.py:317-319.  Covers HT = 2 (nz in 66..128) without the backward's stash / block
-// outputs (lsnf_forward dispatches those calls to lsnf_fwd3.hip).
+// reference model.py:473-483 + train.py:317-319.  Covers HT = 2 (nz in 66..128).  The STASH instantiation of lsnf_fwd3q_kernel also
+// writes the backward's stash (block outputs, sigma tiles, ReLU mask words: bit for bit what lsnf_fwd3.hip writes) from inside the
+// phases -- buffer stores late in each phase, left in flight across the phase barrier by a counted s_waitcnt (stash helpers below);
+// calls with the parameter-gradient dump stay on lsnf_fwd3.hip.
 #include <stdlib.h>
+#include <type_traits>
 #include "lsnf_l16.h"
 
 #if LSNF_L16_PARTS != 3
@@ -47,6 +50,7 @@ struct Fwd3pArgs {
     float* z_out; float* logdet_out; float* ll_out;
     int B, nz, half, n_blocks, vec4;
     double* stats;
+    float* z_saved; float* act_saved;  // lsnf_fwd3q_kernel<.., STASH = true>: block outputs 0..n_blocks-2 and the activation stash (lsnf_layout.h LsnfActLayout)
     unsigned long long* stamps;        // LSNF_STAMPS diagnostic build only: [waves & 2047][64] clock stamps
 };
 
@@ -523,6 +527,68 @@ __device__ __forceinline__ void couple_q16(Tile16& v, const Tile16& t, const Til
     for (int r = r0; r < r0 + 2 * ST; ++r) v.q[qr][r] = (v.q[qr][r] + t.q[qr][r]) * sig.q[qr][r];
 }
 
+// ---- stash writes of the pipelined kernel (STASH instantiation; ST = 2: a wave's 32 rows are one stash tile) -------------------------
+// All of them are raw BUFFER stores: one straight-line instruction each -- no branch splits the pinned schedule of a step --, and the
+// descriptor's byte count drops what must not land: rows past the batch, the tiles of a wave past the batch, and (offset 2^31) the
+// 4-feature groups past `half` of a row's padded second tile.
+#ifndef LSNF_STASH_AUX
+#define LSNF_STASH_AUX 0      // cache-policy bits of the stash stores (experiment knob: 2 = nt)
+#endif
+#ifndef LSNF_STASH_PARTS
+#define LSNF_STASH_PARTS 7    // timing diagnostics (wrong stash): 1 = ReLU masks, 2 = sigma tiles, 4 = block output rows
+#endif
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+struct StashLane { unsigned zoff, soff, moff, msh; };   // per-lane byte offsets: row store, sigma tile, mask words; mask shift 4 * (g >> 1)
+// (every store below has soffset = 0: a uniform byte offset -- the second half of a row, the second sigma tile -- is a second descriptor,
+//  base + off / bytes - off, formed on the scalar unit.  With a REGISTER soffset the compiler's hazard recognizer takes a 128-bit
+//  buffer store for safe against an immediately following VALU write of its data registers; on this chip it is not: the first data
+//  dword of a few lanes then carried the NEW value -- found as 52 wrong rows out of 65 536 in this kernel's first version)
+struct StashRsrc { __amdgpu_buffer_rsrc_t r[2]; };
+__device__ __forceinline__ StashRsrc stash_rsrc(const float* p, unsigned bytes, unsigned second_off) {
+    char* c = reinterpret_cast<char*>(const_cast<float*>(p));
+    return StashRsrc{{__builtin_amdgcn_make_buffer_rsrc(c, 0, (int)bytes, 0x00020000),
+                      __builtin_amdgcn_make_buffer_rsrc(c + second_off, 0, (int)(bytes > second_off ? bytes - second_off : 0u), 0x00020000)}};
+}
+// quad q = 2*ft + st of tile t -> its 16 bytes of row `16*st + n` (the layout of store_tile16 at vec4 == 4)
+template <int HT>
+__device__ __forceinline__ void stash_row_quad(const StashRsrc& rs, const StashLane& sl, int t, int q, const Tile16& x, int nz, int half, int g) {
+    if constexpr (!(LSNF_STASH_PARTS & 4)) return;
+    const int ft = q >> 1, st = q & 1, hh = t / HT, tt = t % HT;
+    unsigned off = sl.zoff;
+    if (st) off += (unsigned)(16 * nz * 4);
+    if (tt > 0) off = (32 * tt + 16 * ft + 4 * g < half) ? off : 0x80000000u;
+    // (the whole vector is cast: __builtin_bit_cast of ONE element of an ext_vector lvalue reads element 0 with this compiler)
+    const u32x4s v = __builtin_bit_cast(u32x4s, x.q[q]);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs.r[hh], off + (unsigned)((32 * tt + 16 * ft) * 4), 0, LSNF_STASH_AUX);
+}
+// sigma quad q of feature tile t (l16_store_sigma's layout: [2*ft + (g >> 1)][16*st + n + 32*(g & 1)][4])
+__device__ __forceinline__ void stash_sigma_quad(const StashRsrc& rs, const StashLane& sl, int t, int q, const Tile16& sg) {
+    if constexpr (!(LSNF_STASH_PARTS & 2)) return;
+    const int ft = q >> 1, st = q & 1;
+    const u32x4s v = __builtin_bit_cast(u32x4s, sg.q[q]);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs.r[t], sl.soff + (unsigned)((2 * ft * 64 + 16 * st) * 16), 0, LSNF_STASH_AUX);
+}
+// ReLU bits of quad q of a hidden tile: bit r = (h[r] > 0).  The sign of (+0 - h) IS that predicate (-(+-0) = +0, no NaNs here), and
+// v_alignbit shifts it in: 2 VALU per value instead of compare + select + shift/or.
+__device__ __forceinline__ void mask_q16(const Tile16& h, int q, unsigned (&mk)[2][2]) {
+    if constexpr (!(LSNF_STASH_PARTS & 1)) return;
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 3; r >= 0; --r) m = __builtin_amdgcn_alignbit(m, __builtin_bit_cast(unsigned, 0.0f - h.q[q][r]), 31);
+    mk[q & 1][q >> 1] = m;
+    asm volatile("" :: "v"(m));
+}
+// the two mask words of a tile (l16_store_masks' format: bit 4*(2*ft + (g >> 1)) + r of word 16*st + n + 32*(g & 1)); all 64 lanes
+// store -- lanes l and l + 32 hold the same word after the exchange and write it to the same address
+__device__ __forceinline__ void stash_mask_words(const StashRsrc& rs, const StashLane& sl, int tile, const unsigned (&mk)[2][2]) {
+    if constexpr (!(LSNF_STASH_PARTS & 1)) return;
+    const unsigned w0 = mk[0][0] | (mk[0][1] << 8), w1 = mk[1][0] | (mk[1][1] << 8);
+    unsigned x = ((w0 << 16) | w1) << sl.msh;
+    x = lsnf_pair_or32(x);
+    __builtin_amdgcn_raw_buffer_store_b32(x >> 16, rs.r[0], sl.moff + (unsigned)(tile * 64 * 4), 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(x & 0xffffu, rs.r[0], sl.moff + (unsigned)((tile * 64 + 16) * 4), 0, 0);
+}
+
 template <int NM, int NV>
 __device__ __forceinline__ void pin_mfma() {       // NM MFMAs, NV VALU spread behind them (the first NV % NM slots carry one more)
     lsnf_static_for<NM>([&](auto mc) {
@@ -584,14 +650,15 @@ __device__ __forceinline__ void run_phase16(Tile16* acc, const float* bias_ptr /
 // S1a: v[0], v[1], natural k order.  Its inputs x[0], x[1] ARE the previous block's v[0], v[1], whose split (S2's input, made
 // under S1b) is simply kept -- no second split; x[2]'s split is finished under steps 0-1, then sigmoid(p1) (2-5), the coupling
 // of x[3] (6-7) and its split (8-11: k-tile 3 starts at step 12) of the previous block
-struct QhS1a {
+struct QhNoStores { static constexpr int stores(int) { return 0; } };     // (stash stores per step: the STASH tables below)
+struct QhS1a : QhNoStores {
     static constexpr int N = 16;
     static constexpr int btile(int acc) { return acc; }
     static constexpr StepDesc at(int i) { return mkstep<4>((i >> 1) & 1, (i >> 1) & 1, i >> 2, i >> 2, i & 1); }
     static constexpr int valu(int i) { return i < 2 ? 22 : (i < 6 ? 28 : (i < 8 ? 16 : (i < 12 ? 22 : 0))); }
 };
 // S1b: v[2], v[3]; split v[0], v[1] (S2's input and the next block's x[0], x[1]) under the last eight steps
-struct QhS1b {
+struct QhS1b : QhNoStores {
     static constexpr int N = 16;
     static constexpr int btile(int acc) { return 2 + acc; }
     static constexpr StepDesc at(int i) { return mkstep<4>((i >> 1) & 1, (i >> 1) & 1, i >> 2, i >> 2, i & 1); }
@@ -599,7 +666,7 @@ struct QhS1b {
 };
 // S2 + S3 out of one buffer [h1_0][h1_1][h2_0][h2_1].  S2 n-major (h1[0] is complete after step 3 and is split under h1[1]'s
 // steps 4-7), S3 k-major (h1[1] is split under its k-tile-0 steps 8-11; h2's halves complete at steps 12..15)
-struct QhS23 {
+struct QhS23 : QhNoStores {
     static constexpr int N = 16;
     static constexpr int btile(int acc) { return 4 + acc; }                 // P1 = 4 (nz in 66..128)
     static constexpr StepDesc at(int i) {
@@ -611,7 +678,7 @@ struct QhS23 {
 };
 // S4 out of one buffer [t0][t1][p0][p1]: k-tile 0 of all four tiles first (h2[1]'s split hides there), then k-tile 1 in the
 // order p0, t0, p1, t1
-struct QhS4 {
+struct QhS4 : QhNoStores {
     static constexpr int N = 16;
     static constexpr int btile(int acc) { return 8 + (acc == 0 ? 2 : (acc == 1 ? 0 : (acc == 2 ? 3 : 1))); }    // P1 + P2 + P3 = 8; accumulators p0, t0, p1, t1
     static constexpr int torder(int j) { return j == 0 ? 2 : (j == 1 ? 0 : (j == 2 ? 3 : 1)); }     // p0, t0, p1, t1 (buffer tiles)
@@ -620,8 +687,41 @@ struct QhS4 {
     static constexpr int valu(int i) { return i < 4 ? 26 : (i < 9 ? 0 : (i < 12 ? 28 : (i == 12 ? 36 : (i == 13 ? 24 : 22)))); }
 };
 
-template <int WT, int NWAVES, int ST>
+// the same tables with the stash writes of the STASH instantiation: ReLU bits 8 VALU per quad, a tile's two mask words 10
+// and stores(i) = the vector-memory STORE instructions of step i (a row or sigma quad 1, a tile's mask words 2).  They sit late in
+// their phase, behind the last piece of the next phase's weight DMA, so that the wait in front of the next barrier can leave them in
+// flight: s_waitcnt vmcnt(N), N = the stores of the steps after that piece (vmcnt retires in issue order; a store is acknowledged
+// 2-2.5 us after its issue under this kernel's write traffic, and vmcnt(0) there cost 4.8 K cycles per block, tools/stamps_fwd3p.py).
+// Every one of these stores is an unconditional straight-line instruction, so N is exact; a smaller N would only wait longer.
+struct QsS1a : QhS1a {
+    static constexpr int valu(int i) { return (i == 6 || i == 7) ? 20 : (i >= 8 && i < 12 ? 23 : QhS1a::valu(i)); }
+    static constexpr int stores(int i) { return (i >= 2 && i < 6) ? 1 : ((i == 6 || i == 7) ? 2 : (i >= 8 && i < 12 ? 1 : 0)); }
+};
+struct QsS1b : QhS1b {
+    static constexpr int valu(int i) { return i < 8 ? (i >= 6 ? 1 : 0) : (i < 14 ? 23 : 22); }
+    static constexpr int stores(int i) { return (i >= 6 && i < 14) ? 1 : 0; }
+};
+struct QsS23 : QhS23 {
+    static constexpr int valu(int i) { return (i >= 4 && i < 12) ? (i == 8 ? 44 : 34) : (i >= 13 ? 34 : 0); }
+    static constexpr int stores(int i) { return i == 8 ? 2 : 0; }
+};
+struct QsS4 : QhS4 {
+    static constexpr int valu(int i) { return i < 4 ? 34 : ((i >= 6 && i < 9) ? 10 + QhS4::valu(i) : QhS4::valu(i)); }
+    static constexpr int stores(int i) { return (i >= 6 && i < 9) ? 2 : ((i >= 9 && i < 13) ? 1 : 0); }
+};
+template <class PH> constexpr int stores_after(int last_dma_step) {
+    int n = 0;
+    for (int i = last_dma_step + 1; i < PH::N; ++i) n += PH::stores(i);
+    return n;
+}
+
+template <int WT, int NWAVES, int ST, bool STASH = false>
 __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pArgs a) {
+    static_assert(!STASH || ST == 2, "the stash tile is a wave's 32 rows");
+    using TS1a = std::conditional_t<STASH, QsS1a, QhS1a>;
+    using TS1b = std::conditional_t<STASH, QsS1b, QhS1b>;
+    using TS23 = std::conditional_t<STASH, QsS23, QhS23>;
+    using TS4 = std::conditional_t<STASH, QsS4, QhS4>;
     using C = Fwd3pCfg<WT>;
     static_assert(WT == 2, "lsnf_fwd3q_kernel: f_width <= 64 instantiation");
     constexpr int THREADS = 64 * NWAVES;
@@ -648,14 +748,21 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
     // hand-over: ~1 200 cycles per phase with one wave per SIMD, tools/stamps_fwd3p.py at 16 384 rows) but one piece at the head
     // of a step of phase k (dma_step), where the issue overlaps the step's MFMAs.  The last phase re-fetches its own weights into
     // the free buffer -- no DMA under a branch; the epilogue waits for it before LDS is reused or released.
-    auto sync_issue = [&](int k) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (STASH: `left` = the stash stores of the phase just run that may stay in flight, see stores_after())
+    auto sync_issue = [&](int k, auto left) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(decltype(left)::value) : "memory");
         __syncthreads();
 #ifdef LSNF_FWD3Q_BURST_DMA
         if (k + 1 < n_phases) issue_kib<48, NWAVES>(phase_src(k + 1), buf0 + ((k + 1) & 1) * SLOT, wave, lane);
 #endif
     };
-    constexpr int PER_WAVE = 48 / NWAVES, EVERY = 16 / PER_WAVE;         // pieces per wave and phase; one every EVERY steps
+    // pieces per wave and phase; one every EVERY steps (STASH: one per step from step 0, so that the steps behind them can hold the stores)
+    constexpr int PER_WAVE = 48 / NWAVES, EVERY = STASH ? 1 : 16 / PER_WAVE, LAST_DMA = (PER_WAVE - 1) * EVERY;
+    using Left0 = std::integral_constant<int, 0>;
+    using LeftS1a = std::integral_constant<int, stores_after<TS1a>(LAST_DMA)>;
+    using LeftS1b = std::integral_constant<int, stores_after<TS1b>(LAST_DMA)>;
+    using LeftS23 = std::integral_constant<int, stores_after<TS23>(LAST_DMA)>;
+    using LeftS4 = std::integral_constant<int, stores_after<TS4>(LAST_DMA)>;
     const float* dma_src = nullptr; float* dma_dst = nullptr;
     auto dma_arm = [&](int k) {                                          // phase k is about to run: its steps carry phase k+1's pieces
         dma_src = phase_src(k + 1 < n_phases ? k + 1 : k);
@@ -704,7 +811,19 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
 #pragma unroll
     for (int st = 0; st < 2; ++st) ell[st] = (st < ST && a.objective) ? a.objective[rows[st]] : 0.0f;
     float ss01[2] = {0.0f, 0.0f};
-    sync_issue(0);
+    // STASH: per-lane byte offsets of the stash writes (rows of this wave in a (B, nz) block; this wave's stash tile), and the byte
+    // counts of the buffer descriptors
+    StashLane sl0 = {0u, 0u, 0u, 0u};
+    const LsnfActLayout al = lsnf_act_layout(a.B, HT, WT);
+    const unsigned zbytes = (unsigned)a.B * (unsigned)a.nz * 4u, abytes = (unsigned)(al.per_block * 4);
+    if constexpr (STASH) {
+        const unsigned tile_byte = (unsigned)(wbase >> 5) * (unsigned)(al.per_tile * 4), L = (unsigned)(n + 32 * (g & 1));
+        sl0.zoff = ((unsigned)(wbase + n) * (unsigned)a.nz + 4u * g) * 4u;
+        sl0.soff = tile_byte + ((unsigned)(g >> 1) * 64u + L) * 16u;
+        sl0.moff = tile_byte + (unsigned)(al.mask_off * 4) + L * 4u;
+        sl0.msh = 4u * (g >> 1);
+    }
+    sync_issue(0, Left0{});
     P_STAMP(1, "s_memtime");
 
     for (int blk = 0; blk < a.n_blocks; ++blk) {
@@ -714,29 +833,52 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
         SplitTile16 vh[4];                          // S2+S3 inputs: split v[0], v[1], h1[0], h1[1]
         SplitTile16 h2s[WT];
         Tile16 hh[4], tp[4];                        // hh: h1[0], h1[1], h2[0], h2[1];  tp: p0, t0, p1, t1
+        // STASH: where this block's output rows / stash tiles go, and the previous block's (whose second half is finished under this
+        // block's S1a).  Block 0 has no predecessor: those stores go to rows of z_out and to block 0's own tiles, both rewritten later
+        // by the same wave; the last block of the call writes its rows to z_out.
+        // A part of the stash the caller did not ask for (z_saved or act_saved NULL) gets a descriptor of zero bytes: same instructions,
+        // every store dropped.
+        const bool zs = STASH && a.z_saved != nullptr, as = STASH && a.act_saved != nullptr;
+        const float* zc = more ? (zs ? a.z_saved + (size_t)blk * a.B * a.nz : a.z_out) : a.z_out;
+        const float* zp = blk > 0 ? (zs ? a.z_saved + (size_t)(blk - 1) * a.B * a.nz : a.z_out) : a.z_out;
+        const StashRsrc rs_zc = stash_rsrc(zc, (more && !zs) ? 0u : zbytes, (unsigned)a.half * 4u);
+        const StashRsrc rs_zp = stash_rsrc(zp, (blk > 0 && !zs) ? 0u : zbytes, (unsigned)a.half * 4u);
+        const StashRsrc rs_ac = stash_rsrc(as ? a.act_saved + (size_t)blk * al.per_block : a.z_out, as ? abytes : 0u, 4096u);
+        const StashRsrc rs_ap = stash_rsrc(as ? a.act_saved + (size_t)(blk > 0 ? blk - 1 : 0) * al.per_block : a.z_out, as ? abytes : 0u, 4096u);
+        // (opaque per block: the constant parts of the store offsets then fold into the instructions' immediate fields instead of being
+        //  formed once, ahead of the loop, in thirty registers)
+        StashLane sl = sl0;
+        if constexpr (STASH) asm volatile("" : "+v"(sl.zoff), "+v"(sl.soff), "+v"(sl.moff));
+        unsigned mk1[2][2], mk2[2][2], mk3[2][2];   // ReLU bits of h1[1], h2[0], h2[1] until their words are stored (early in S4: see sync_issue)
 
         if (blk == 1) P_STAMP(10, "s_memtime");
         // ---- S1a: v[0,1]  (model.py:187; actnorm :244,268 folded); carries the end of the previous block's coupling (:414-418) ----
         {
             const float* bv = bias_lane_ptr(cb, g);
-            if (k0 > 0) sync_issue(k0);
+            if (k0 > 0) sync_issue(k0, LeftS4{});
             dma_arm(k0);
-            run_phase16<QhS1a, ST>(v, bv, xs, buf0 + (k0 & 1) * SLOT, lane, [&](auto ic) {
+            run_phase16<TS1a, ST>(v, bv, xs, buf0 + (k0 & 1) * SLOT, lane, [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
+                if constexpr (STASH && i >= 8 && i < 12) stash_row_quad<HT>(rs_zp, sl, 2, i - 8, v[2], a.nz, a.half, g);   // x[2] of the previous block
                 if constexpr (i < 2) split_q16<false, ST>(v[2], 2 + i, xs[2]);                 // x[2]: k-tile 2 starts at step 8
-                else if constexpr (i < 6) sigmoid_q16<ST>(p1, i - 2, lsum);
-                else if constexpr (i < 8) { couple_q16<ST>(v[3], t1, p1, 2 * (i - 6)); couple_q16<ST>(v[3], t1, p1, 2 * (i - 6) + 1); }
-                else if constexpr (i < 12) split_q16<false, ST>(v[3], i - 8, xs[3]);           // x[3]: k-tile 3 starts at step 12
+                else if constexpr (i < 6) {
+                    sigmoid_q16<ST>(p1, i - 2, lsum);
+                    if constexpr (STASH) stash_sigma_quad(rs_ap, sl, 1, i - 2, p1);
+                } else if constexpr (i < 8) {
+                    couple_q16<ST>(v[3], t1, p1, 2 * (i - 6)); couple_q16<ST>(v[3], t1, p1, 2 * (i - 6) + 1);
+                    if constexpr (STASH) { stash_row_quad<HT>(rs_zp, sl, 3, 2 * (i - 6), v[3], a.nz, a.half, g); stash_row_quad<HT>(rs_zp, sl, 3, 2 * (i - 6) + 1, v[3], a.nz, a.half, g); }
+                } else if constexpr (i < 12) split_q16<false, ST>(v[3], i - 8, xs[3]);         // x[3]: k-tile 3 starts at step 12
             }, dma_step);
         }
         if (blk == 1) P_STAMP(11, "s_memtime");
         // ---- S1b: v[2,3]; split v[0], v[1]: S2's input AND the next block's x[0], x[1] ----
         {
             const float* bv = bias_lane_ptr(cb, g);
-            sync_issue(k0 + 1);
+            sync_issue(k0 + 1, LeftS1a{});
             dma_arm(k0 + 1);
-            run_phase16<QhS1b, ST>(v + 2, bv, xs, buf0 + ((k0 + 1) & 1) * SLOT, lane, [&](auto ic) {
+            run_phase16<TS1b, ST>(v + 2, bv, xs, buf0 + ((k0 + 1) & 1) * SLOT, lane, [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
+                if constexpr (STASH && i >= 6 && i < 14) stash_row_quad<HT>(rs_zc, sl, (i - 6) >> 2, (i - 6) & 3, v[(i - 6) >> 2], a.nz, a.half, g);   // the v1 half of this block's output
                 if constexpr (i >= 8) split_q16<false, ST>(v[(i - 8) >> 2], i & 3, vh[(i - 8) >> 2]);    // (xs[0], xs[1] are dead by now: k order)
             }, dma_step);
         }
@@ -748,7 +890,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
             const int smp[2] = {wbase + (ln & 15), wbase + 16 + (ln & 15)};
 #pragma unroll
             for (int t = 0; t < HT; ++t) {
-                store_tile16<HT, ST>(t, v[t], a.z_out, smp, live, a.nz, a.half, g, a.vec4);
+                if constexpr (!STASH) store_tile16<HT, ST>(t, v[t], a.z_out, smp, live, a.nz, a.half, g, a.vec4);    // (STASH: stored under S1b)
 #pragma unroll
                 for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
@@ -763,13 +905,19 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
         {
             static_assert(C::P1 == 4 && C::P2 == 2 && C::P3 == 2, "bias tile indices of the phase tables");
             const float* bv = bias_lane_ptr(cb, g);
-            sync_issue(k0 + 2);
+            sync_issue(k0 + 2, LeftS1b{});
             dma_arm(k0 + 2);
-            run_phase16<QhS23, ST>(hh, bv, vh, buf0 + ((k0 + 2) & 1) * SLOT, lane, [&](auto ic) {
+            run_phase16<TS23, ST>(hh, bv, vh, buf0 + ((k0 + 2) & 1) * SLOT, lane, [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 if constexpr (i >= 4 && i < 8) split_q16<true, ST>(hh[0], i - 4, vh[2]);      // h1[0] under h1[1]'s steps
                 if constexpr (i >= 8 && i < 12) split_q16<true, ST>(hh[1], i - 8, vh[3]);     // h1[1] under S3's k-tile 0
                 if constexpr (i >= 13) split_q16<true, ST>(hh[2], i - 13, h2s[0]);             // h2[0]: its halves complete after steps 12, 13
+                if constexpr (STASH) {
+                    if constexpr (i >= 4 && i < 8) mask_q16(hh[0], i - 4, mk3);               // (mk3 is free until S4)
+                    if constexpr (i == 8) stash_mask_words(rs_ac, sl, 0, mk3);
+                    if constexpr (i >= 8 && i < 12) mask_q16(hh[1], i - 8, mk1);
+                    if constexpr (i >= 13) mask_q16(hh[2], i - 13, mk2);
+                }
             }, dma_step);
         }
         if (blk == 1) P_STAMP(13, "s_memtime");
@@ -780,13 +928,20 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
             static_assert(B4 == 8, "bias tile indices of the phase tables");
             const float* bv = bias_lane_ptr(cb, g);
             split_q16<true, ST>(hh[2], 3, h2s[0]);       // (the last quad of h2[0]: exposed, S4's first step needs it)
-            sync_issue(k0 + 3);
+            if constexpr (STASH) mask_q16(hh[2], 3, mk2);
+            sync_issue(k0 + 3, LeftS23{});
             dma_arm(k0 + 3);
-            run_phase16<QhS4, ST>(tp, bv, h2s, buf0 + ((k0 + 3) & 1) * SLOT, lane, [&](auto ic) {
+            run_phase16<TS4, ST>(tp, bv, h2s, buf0 + ((k0 + 3) & 1) * SLOT, lane, [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 if constexpr (i < 4) split_q16<true, ST>(hh[3], i, h2s[1]);                    // h2[1] under k-tile 0
+                if constexpr (STASH) {
+                    if constexpr (i < 4) mask_q16(hh[3], i, mk3);
+                    if constexpr (i == 6) stash_mask_words(rs_ac, sl, 1, mk1);
+                    if constexpr (i == 7) stash_mask_words(rs_ac, sl, WT + 0, mk2);
+                    if constexpr (i == 8) stash_mask_words(rs_ac, sl, WT + 1, mk3);
+                }
                 // k-tile 1: p0's halves are complete after steps 8, 9; t0's after 10, 11; p1's after 12, 13; t1's after 14, 15
-                if constexpr (i >= 9 && i < 13) sigmoid_q16<ST>(tp[0], i - 9, lsum);
+                if constexpr (i >= 9 && i < 13) { sigmoid_q16<ST>(tp[0], i - 9, lsum); if constexpr (STASH) stash_sigma_quad(rs_ac, sl, 0, i - 9, tp[0]); }
                 if constexpr (i == 12) couple_q16<ST>(v[2], tp[1], tp[0], 0);
                 if constexpr (i == 13) { couple_q16<ST>(v[2], tp[1], tp[0], 1); couple_q16<ST>(v[2], tp[1], tp[0], 2); couple_q16<ST>(v[2], tp[1], tp[0], 3); }
                 if constexpr (i >= 14) split_q16<false, ST>(v[2], i - 14, xs[2]);
@@ -799,6 +954,12 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
     // the last block's x[3] (no S1a follows)
 #pragma unroll
     for (int q = 0; q < 4; ++q) { sigmoid_q16<ST>(p1, q, lsum); couple_q16<ST>(v[3], t1, p1, q); }
+    if constexpr (STASH) {
+        const bool as = a.act_saved != nullptr;
+        const StashRsrc rs_al = stash_rsrc(as ? a.act_saved + (size_t)(a.n_blocks - 1) * al.per_block : a.z_out, as ? abytes : 0u, 4096u);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) stash_sigma_quad(rs_al, sl0, 1, q, p1);
+    }
 #pragma unroll
     for (int st = 0; st < ST; ++st) ell[st] = ell[st] + -0.6931471805599453f * l16_group_sum(lsum[st]);
 
@@ -849,12 +1010,12 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
     P_STAMP(51, "s_memrealtime");
 }
 
-template <int WT, int NWAVES, int ST>
+template <int WT, int NWAVES, int ST, bool STASH = false>
 hipError_t launch_fwd3q_w(const Fwd3pArgs& a, hipStream_t stream) {
     using C = Fwd3pCfg<WT>;
     const size_t lds = ((size_t)a.n_blocks * C::CONST_FLOATS + 2 * (size_t)C::SLOT3) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = lsnf_fwd3q_kernel<WT, NWAVES, ST>;
+    auto kern = lsnf_fwd3q_kernel<WT, NWAVES, ST, STASH>;
     static unsigned long long lds_ok = 0;
     if (hipError_t e = lsnf_allow_big_lds((const void*)kern, &lds_ok); e != hipSuccess) return e;
     const unsigned grid = (unsigned)((a.B + 16 * ST * NWAVES - 1) / (16 * ST * NWAVES));
@@ -907,12 +1068,19 @@ hipError_t lsnf_launch_forward3p(const LsnfGeo& g, const float* plan, int first_
 hipError_t lsnf_launch_forward3q(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                  const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                  float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4, hipStream_t stream) {
-    if (g.HT != 2 || g.WT != 2 || z_saved != nullptr || act_saved != nullptr) return hipErrorInvalidValue;
+    if (g.HT != 2 || g.WT != 2) return hipErrorInvalidValue;
+    // with the stash, or a part of it (STASH instantiation: buffer stores of whole 16-byte groups through 32-bit offsets): rows that take
+    // 16-byte accesses, and a block of rows / of stash tiles below 2 GiB
+    const bool stash = act_saved != nullptr || z_saved != nullptr;
+    if (stash && (vec4 != 4 || (size_t)B * g.nz * 4 >= (1ull << 31) || lsnf_act_layout(B, g.HT, g.WT).per_block * 4 >= (1ull << 31) ||
+                  (((size_t)act_saved | (size_t)z_saved | (size_t)z_out) & 15)))
+        return hipErrorInvalidValue;
     Fwd3pArgs a;
     a.consts = plan + g.off_fwd_const + (size_t)first_block * g.fwd_const_floats;
     a.panels3 = plan + g.off_f3b_panels + (size_t)first_block * g.f3_block_floats;
     a.z_in = z_in; a.objective = objective; a.z_out = z_out; a.logdet_out = logdet_out; a.ll_out = ll_out;
     a.B = B; a.nz = g.nz; a.half = g.half; a.n_blocks = n_blocks; a.vec4 = vec4; a.stats = stats;
+    a.z_saved = z_saved; a.act_saved = act_saved ? act_saved + (size_t)first_block * lsnf_act_layout(B, g.HT, g.WT).per_block : nullptr;
     a.stamps = nullptr;
 #ifdef LSNF_STAMPS
     { extern unsigned long long* g_lsnf_stamps;
@@ -923,6 +1091,7 @@ hipError_t lsnf_launch_forward3q(const LsnfGeo& g, const float* plan, int first_
     // per wave so that the grid still covers the chip -- 8 waves x 16 rows down to 16 384 rows, 4 waves x 16 rows below
     static const char* shape = getenv("LSNF_FWD3Q_SHAPE");     // experiment knob (tools/shard_times.py): "82", "42", "81", "41"
     const int sh = shape ? atoi(shape) : (B > 128 * 256 ? 82 : (B > 64 * 256 ? 81 : 41));
+    if (stash) return (sh == 82) ? launch_fwd3q_w<2, 8, 2, true>(a, stream) : launch_fwd3q_w<2, 4, 2, true>(a, stream);
     if (sh == 82) return launch_fwd3q_w<2, 8, 2>(a, stream);
     if (sh == 42) return launch_fwd3q_w<2, 4, 2>(a, stream);
     if (sh == 81) return launch_fwd3q_w<2, 8, 1>(a, stream);

@@ -375,3 +375,43 @@ def test_split_bf16_dynamic_range(lsnf, gpu_device, z_scale, w_scale):
     assert max(err.values()) <= 1e-5, err
     assert max(err["bf16x3"], err["bf16x3_phased"]) <= 2.0 * err["fp32"] + 1e-7, err
     assert err["fp16x2"] <= 3.0 * err["fp32"] + 1e-7, err
+
+
+@pytest.mark.parametrize("nz,width,depth,B", [(128, 64, 5, 40001), (104, 48, 3, 33000), (128, 64, 1, 32800), (128, 64, 2, 70001)])
+def test_pipelined_forward_writes_the_phase_separated_stash(lsnf, gpu_device, nz, width, depth, B):
+    """The stash-writing instantiation of the software-pipelined forward (lsnf_fwd3q_kernel<.., STASH>: buffer stores inside the
+    MFMA phases, left in flight across the phase barriers) against the phase-separated kernel (math mode BF16X3_PHASED) on the
+    same inputs: block outputs, sigma tiles and ReLU mask words bit for bit (what the backward reads does not depend on which
+    forward wrote it), with every combination of the two optional buffers, ragged batches (waves and rows past the batch: their
+    stores are dropped by the buffer descriptors) and a padded second feature tile (nz = 104)."""
+    F = lsnf.flow
+    p = O.init_params(nz, width, depth, seed=11)
+    plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
+    z = torch.randn(B, nz, generator=torch.Generator().manual_seed(B)).to(gpu_device)
+    prev_small, prev_math = F.set_small_batch_max(0), F.set_math_mode(-1)
+    try:
+        def run(mode, want_act, want_saved):
+            F.set_math_mode(mode)
+            act = F.new_act_saved(plan, B, gpu_device) if want_act else None
+            if act is not None:
+                act.fill_(float("nan"))
+            saved = torch.full((depth - 1, B, nz), float("nan"), device=gpu_device) if want_saved else None
+            guard = torch.full((4096,), 7.0, device=gpu_device)          # (allocated right behind: a store past the batch would land here)
+            out = lsnf.forward(plan, z, act_saved=act, z_saved_out=saved)
+            torch.cuda.synchronize()
+            assert bool((guard == 7.0).all())
+            return out[0], out[1], out[2], saved, act
+        ref = run(F.MATH_BF16X3_PHASED, True, True)
+        plain = run(F.MATH_BF16X3, False, False)
+        for want_act, want_saved in ((True, True), (False, True), (True, False)):
+            got = run(F.MATH_BF16X3, want_act, want_saved)
+            assert torch.equal(got[0], ref[0])                              # z1: the same arithmetic in both kernels
+            assert torch.equal(got[0], plain[0]) and torch.equal(got[1], plain[1]) and torch.equal(got[2], plain[2])   # stash or not: one kernel
+            assert (got[2] - ref[2]).abs().max().item() <= 1e-4 * ref[2].abs().max().item()   # (the log-det sum is ordered differently)
+            if want_saved and depth > 1:
+                assert torch.equal(got[3], ref[3])
+            if want_act:
+                assert torch.equal(got[4].view(torch.int32), ref[4].view(torch.int32))
+    finally:
+        F.set_small_batch_max(prev_small)
+        F.set_math_mode(prev_math)

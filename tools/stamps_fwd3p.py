@@ -17,17 +17,21 @@ hip = ctypes.CDLL("libamdhip64.so")
 which = sys.argv[1] if len(sys.argv) > 1 else "q"          # p: lsnf_fwd3p_kernel (32x32x16), q: lsnf_fwd3q_kernel (16x16x32)
 lsnf_amd.flow.set_math_mode(lsnf_amd.flow.MATH_BF16X3 if which == "q" else lsnf_amd.flow._MATH_X_BF16X3_PIPE)
 lsnf_amd.flow.set_small_batch_max(0)
+stash = len(sys.argv) > 3 and sys.argv[3] == "stash"         # the stash-writing instantiation (lsnf_fwd3q_kernel<.., STASH>)
+act = lsnf_amd.flow.new_act_saved(plan, BROWS, dev) if stash else None
+saved = torch.empty(bench.DEPTH - 1, BROWS, bench.NZ, device=dev) if stash else None
 t0 = time.perf_counter(); n = 0
 while time.perf_counter() - t0 < 2.5:
     for _ in range(200):
-        lsnf_amd.forward(plan, z, out=out)
+        lsnf_amd.forward(plan, z, out=out, act_saved=act, z_saved_out=saved)
     torch.cuda.synchronize(); n += 200
 buf = (ctypes.c_ulonglong * (2048 * 64))()
 hip.hipMemcpy(buf, ctypes.c_void_p(lib.lsnf_debug_stamps()), ctypes.c_size_t(2048 * 64 * 8), 2)
 s = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 64).astype(np.int64)
 cyc = (s[:, 41] - s[:, 0]).astype(np.float64); rt = (s[:, 51] - s[:, 50]).astype(np.float64)
 ok = rt > 0
-print(f"lsnf_fwd3{which}_kernel after {n} launches: in-kernel clock median {np.median(cyc[ok] / rt[ok]) * 0.1:.3f} GHz; wave lifetime "
+tag = " with stash" if stash else ""
+print(f"lsnf_fwd3{which}_kernel{tag} after {n} launches: in-kernel clock median {np.median(cyc[ok] / rt[ok]) * 0.1:.3f} GHz; wave lifetime "
       f"median {np.median(rt[ok]) / 100:.1f} us = {np.median(cyc[ok]):.0f} cycles")
 print(f"  prologue (row loads, first split, barrier 0) {np.median((s[:, 1] - s[:, 0])[ok]):9.0f} cycles")
 print(f"  block 0                               {np.median((s[:, 10] - s[:, 1])[ok]):9.0f}")
