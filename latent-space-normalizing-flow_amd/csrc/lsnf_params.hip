@@ -42,6 +42,10 @@ hipError_t lsnf_launch_backward3_z(const LsnfGeo& g, const float* plan, int B, c
                                    float* g_z_in, int vec4, hipStream_t stream, const LsnfLangevinArgs* lv,
                                    float* dump, float* gl_total);
 
+// lsnf_params3.hip: the same contraction on the bf16 matrix pipe (large batches); hipErrorInvalidValue = not covered
+hipError_t lsnf_launch_contract_x3(const float* z_in, const float* z_out, const float* z_saved, const float* dump, float* fold,
+                                   int B, int nz, int half, int width, int depth, int chunk_override, hipStream_t stream);
+
 namespace {
 
 struct TnArgs {
@@ -440,7 +444,16 @@ hipError_t lsnf_launch_backward_params(const LsnfGeo& g, const float* plan, cons
     t.abl = knob_abl;
     if (knob_chunk > 0) t.chunk = knob_chunk;
     const unsigned chunks = (unsigned)((B + t.chunk - 1) / t.chunk);
-    if (B >= 4096 && !knob_plain) {
+    // Large batches on the fast path (bf16x3-family math: act_saved given): the contraction on the bf16 matrix pipe, operands read once
+    // (lsnf_params3.hip); LSNF_TN_X3=0 keeps the fp32-MFMA kernel below.
+    static const bool knob_x3 = [] { const char* e = getenv("LSNF_TN_X3"); return e ? atoi(e) != 0 : true; }();
+    e = hipErrorInvalidValue;
+    if (act_saved && knob_x3 && !knob_plain && B >= 12288 && vec4 == 4)
+        e = lsnf_launch_contract_x3(z_in, z_out, z_saved, dump, fold, B, g.nz, g.half, g.width, g.depth, knob_chunk, stream);
+    if (e == hipSuccess) {
+    } else if (e != hipErrorInvalidValue) {
+        return e;
+    } else if (B >= 4096 && !knob_plain) {
         // every row the tasks read starts 16-byte aligned iff nz, width and half are multiples of 4 (z tensors: the caller's
         // alignment is folded into vec4; the dump rows start at 16-byte aligned offsets of the 16-byte aligned workspace)
         const bool a4 = vec4 == 4 && g.nz % 4 == 0 && g.width % 4 == 0 && g.half % 4 == 0;
