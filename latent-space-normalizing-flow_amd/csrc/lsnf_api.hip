@@ -35,7 +35,7 @@ hipError_t lsnf_launch_forward(const LsnfGeo& g, const float* plan, int first_bl
 hipError_t lsnf_launch_forward3(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                 const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                 float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
-                                int shape16, int fixup, hipStream_t stream, float* hdump = nullptr);
+                                int shape16, int fixup, hipStream_t stream, float* hdump = nullptr, int hdump_tiled = 0);
 hipError_t lsnf_launch_forward3q(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                  const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                  float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4, hipStream_t stream);
@@ -45,7 +45,7 @@ hipError_t lsnf_launch_forward3p(const LsnfGeo& g, const float* plan, int first_
 hipError_t lsnf_launch_forward2h(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                  const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                  float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
-                                 int shape16, int fixup, hipStream_t stream, float* hdump = nullptr);
+                                 int shape16, int fixup, hipStream_t stream, float* hdump = nullptr, int hdump_tiled = 0);
 hipError_t lsnf_launch_small3_forward(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                       const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                       float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
@@ -81,7 +81,8 @@ hipError_t lsnf_launch_small3_backward_z(const LsnfGeo& g, const float* plan, in
 hipError_t lsnf_launch_backward3_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
                                    const float* act_saved, const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
                                    float* g_z_in, int vec4, hipStream_t stream, const LsnfLangevinArgs* lv,
-                                   float* dump = nullptr, float* gl_total = nullptr);
+                                   float* dump = nullptr, float* gl_total = nullptr, int dump_tiled = 0);
+bool lsnf_contract_x3_covers(int B, int nz, int half, int width, const float* z_in, const float* z_out, const float* z_saved);
 hipError_t lsnf_launch_backward_params(const LsnfGeo& g, const float* plan, const float* const* params_host,
                                        float* const* grads_host, int B, const float* z_in, const float* z_out,
                                        const float* z_saved, const float* g_z1, const float* g_logdet, int ll_mode,
@@ -269,6 +270,16 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
     if (z_saved == nullptr && act_saved == nullptr && small_batch_setting() == LSNF_SMALL_BATCH_AUTO && small_max > 8192 &&
         math == LSNF_MATH_BF16X3 && g.HT == 2 && g.WT == 2)
         small_max = 8192;
+    // Parameter-gradient dump: from LSNF_X3_MIN_ROWS rows the batch contraction of lsnf_params3.hip may read it and asks the workspace's
+    // tag word which form h1 / h2 have -- tiled (whole 1 KiB stores) when the bf16x3 throughput forward writes them, row-major otherwise
+    int hdump_tiled = 0;
+    if (hdump && B >= LSNF_X3_MIN_ROWS) {
+        hdump_tiled = (B > small_max && split && math != LSNF_MATH_X_BF16X3_32 && lsnf_dump_can_tile(nz, width) &&
+                       lsnf_contract_x3_covers(B, nz, g.half, width, z_in, z_out, z_saved)) ? 1 : 0;
+        if (hipMemsetD32Async((hipDeviceptr_t)(params_workspace + lsnf_params_workspace_tag(nz, width, depth, B)), hdump_tiled, 1,
+                              (hipStream_t)stream) != hipSuccess)
+            return fail(LSNF_E_HIP, "lsnf_forward: hipMemsetD32Async(workspace tag) failed");
+    }
     if (B <= small_max) {
         e = hipErrorInvalidValue;
         if (l16_math())                           // latency forward on the bf16 pipe: 16-sample workgroups (lsnf_small3_fwd.hip)
@@ -300,7 +311,7 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
                                       z_saved, act_saved, stats, vec4, (hipStream_t)stream);
         if (e == hipErrorInvalidValue && (split || math == LSNF_MATH_FP16X2))   // error-free split on the bf16 matrix pipe (lsnf_fwd3.hip)
             e = lsnf_launch_forward3(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
-                                     z_saved, act_saved, stats, vec4, math != LSNF_MATH_X_BF16X3_32, /*fixup=*/0, (hipStream_t)stream, hdump);
+                                     z_saved, act_saved, stats, vec4, math != LSNF_MATH_X_BF16X3_32, /*fixup=*/0, (hipStream_t)stream, hdump, hdump_tiled);
         if (e == hipErrorInvalidValue && !hdump)  // fp32 MFMA kernel (also: stacks too deep for fwd3's LDS budget)
             e = lsnf_launch_forward(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
                                     z_saved, act_saved, stats, vec4, (hipStream_t)stream);

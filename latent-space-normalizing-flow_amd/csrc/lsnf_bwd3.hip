@@ -32,7 +32,8 @@ struct Bwd3Args {
     float step, ll_scale;
     LsnfRngArgs rng;
     int ll_mode, B, nz, half, depth, vec4;
-    float* dump; float* gl_total; int width;      // DUMP variant (parameter gradients, lsnf_params.hip): per block g_v, g_a1, g_a2,
+    float* dump; float* gl_total; int width; int dump_tiled;     // dump_tiled: the g arrays in the tiled form (lsnf_l16.h l16_store_tiled), g_v as its first half only
+         // DUMP variant (parameter gradients, lsnf_params.hip): per block g_v, g_a1, g_a2,
                                                   // g_t, g_p written for the batch contraction; G = sum_b dL/dlogdet_b
 };
 
@@ -104,6 +105,17 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_bwd3_kernel(const Bwd3Args a)
     auto zero = [](int) { return lsnf_zero16(); };
     auto keep = [](f32x16 acc, int) { return acc; };
     const LsnfDumpLayout dl = lsnf_dump_layout(a.B, a.nz, a.width);
+    // tiled dump: this wave's 32-sample tile (not the clamped one: a wave past the batch stores nothing); rows past the batch inside
+    // the last tile are written as zeros (they are inside the arrays and the contraction sums whole tiles)
+    const size_t tile32 = (size_t)blockIdx.x * NW + wave;
+    const bool tile_ok = tile32 * 32 < (size_t)a.B, all_live = live[0] && live[1];
+    auto dead_rows_zero = [&](const f32x16& x) {
+        if (__builtin_amdgcn_ballot_w64(!all_live) == 0) return x;         // (wave-uniform: every tile but the batch's last)
+        f32x16 y = x;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = live[(r >> 2) & 1] ? x[r] : 0.0f;
+        return y;
+    };
     const bool w4 = (a.width & 3) == 0, h4 = (a.half & 3) == 0;
     if constexpr (DUMP) {   // G = sum_b dL/dlogdet_b: one atomic per wave
         float t = 0.0f;
@@ -141,8 +153,12 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_bwd3_kernel(const Bwd3Args a)
         if constexpr (DUMP) {
 #pragma unroll
             for (int t = 0; t < HT; ++t) {
-                l16_store_plain(tp[t], dmp + dl.off_gt, sample, live, a.half, t, g, h4);
-                l16_store_plain(tp[HT + t], dmp + dl.off_gp, sample, live, a.half, t, g, h4);
+                if (a.dump_tiled) {
+                    if (tile_ok) { l16_store_tiled(dead_rows_zero(tp[t]), dmp + dl.off_gt, tile32, a.half, t, n, g); l16_store_tiled(dead_rows_zero(tp[HT + t]), dmp + dl.off_gp, tile32, a.half, t, n, g); }
+                } else {
+                    l16_store_plain(tp[t], dmp + dl.off_gt, sample, live, a.half, t, g, h4);
+                    l16_store_plain(tp[HT + t], dmp + dl.off_gp, sample, live, a.half, t, g, h4);
+                }
             }
         }
         // ---- B4: g_a2 = ([W3s W3p][g_t; g_p]) gated by h2 > 0 ----
@@ -156,7 +172,10 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_bwd3_kernel(const Bwd3Args a)
         for (int t = 0; t < WT; ++t) gh2[t] = lsnf_apply_mask16(gh2[t], m2[t]);
         if constexpr (DUMP) {
 #pragma unroll
-            for (int t = 0; t < WT; ++t) l16_store_plain(gh2[t], dmp + dl.off_ga2, sample, live, a.width, t, g, w4);
+            for (int t = 0; t < WT; ++t) {
+                if (a.dump_tiled) { if (tile_ok) l16_store_tiled(dead_rows_zero(gh2[t]), dmp + dl.off_ga2, tile32, a.width, t, n, g); }
+                else l16_store_plain(gh2[t], dmp + dl.off_ga2, sample, live, a.width, t, g, w4);
+            }
         }
         // ---- B3: g_a1 = (W2' g_a2) gated by h1 > 0 ----
         f32x16 gh1[WT];
@@ -169,7 +188,10 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_bwd3_kernel(const Bwd3Args a)
         for (int t = 0; t < WT; ++t) gh1[t] = lsnf_apply_mask16(gh1[t], m1[t]);
         if constexpr (DUMP) {
 #pragma unroll
-            for (int t = 0; t < WT; ++t) l16_store_plain(gh1[t], dmp + dl.off_ga1, sample, live, a.width, t, g, w4);
+            for (int t = 0; t < WT; ++t) {
+                if (a.dump_tiled) { if (tile_ok) l16_store_tiled(dead_rows_zero(gh1[t]), dmp + dl.off_ga1, tile32, a.width, t, n, g); }
+                else l16_store_plain(gh1[t], dmp + dl.off_ga1, sample, live, a.width, t, g, w4);
+            }
         }
         // ---- B2: g_v1 = g_x1 (direct) + W1' g_a1 ;  gv = [g_v1 ; g_v2] ----
         f32x16 gv[NZT];
@@ -183,7 +205,11 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_bwd3_kernel(const Bwd3Args a)
         for (int t = 0; t < HT; ++t) gv[HT + t] = tp[t];
         if constexpr (DUMP) {
 #pragma unroll
-            for (int t = 0; t < NZT; ++t) l16_store_tile<HT>(t, gv[t], dmp + dl.off_gv, sample, live, a.nz, a.half, g, vec4);
+            for (int t = 0; t < NZT; ++t) {
+                // (tiled: g_v1 only, as a (B, half) array -- the second half IS g_t, which the contraction reads from its own array)
+                if (a.dump_tiled) { if (t < HT && tile_ok) l16_store_tiled(dead_rows_zero(gv[t]), dmp + dl.off_gv, tile32, a.half, t, n, g); }
+                else l16_store_tile<HT>(t, gv[t], dmp + dl.off_gv, sample, live, a.nz, a.half, g, vec4);
+            }
         }
         // ---- B1: g_x = Wa [g_v1; g_v2] ----
         {
@@ -284,15 +310,15 @@ hipError_t launch_bwd3(const Bwd3Args& a, hipStream_t stream) {
 hipError_t lsnf_launch_backward3_z_wide(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
                                         const float* act_saved, const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
                                         float* g_z_in, int vec4, hipStream_t stream, const LsnfLangevinArgs* lv,
-                                        float* dump, float* gl_total);
+                                        float* dump, float* gl_total, int dump_tiled);
 #endif
 hipError_t LSNF_BWD3_ENTRY(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
                            const float* act_saved, const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
                            float* g_z_in, int vec4, hipStream_t stream, const LsnfLangevinArgs* lv,
-                           float* dump, float* gl_total) {
+                           float* dump, float* gl_total, int dump_tiled) {
     if (!act_saved) return hipErrorInvalidValue;
     Bwd3Args a;
-    a.dump = dump; a.gl_total = gl_total; a.width = g.width;
+    a.dump = dump; a.gl_total = gl_total; a.width = g.width; a.dump_tiled = dump_tiled;
     a.panels = plan + g.off_b3b_panels;
     a.z_out = z_out; a.z_saved = z_saved; a.act_saved = act_saved; a.g_z1 = g_z1; a.g_logdet = g_logdet; a.g_z_in = g_z_in;
     a.z_cur = nullptr; a.grad_g = nullptr; a.noise = nullptr; a.z_new = nullptr; a.gf_norm = nullptr; a.gg_norm = nullptr; a.step = 0.f;
@@ -306,7 +332,7 @@ hipError_t LSNF_BWD3_ENTRY(const LsnfGeo& g, const float* plan, int B, const flo
     if (g.HT == 1 && g.WT == 1) return launch_bwd3<Bwd3Cfg<1, 1>>(a, stream);
     if (g.HT == 2 && g.WT == 2) return launch_bwd3<Bwd3Cfg<2, 2>>(a, stream);
     if (g.HT == 2 && g.WT == 4)
-        return lsnf_launch_backward3_z_wide(g, plan, B, z_out, z_saved, act_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, vec4, stream, lv, dump, gl_total);
+        return lsnf_launch_backward3_z_wide(g, plan, B, z_out, z_saved, act_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, vec4, stream, lv, dump, gl_total, dump_tiled);
 #endif
     return hipErrorInvalidValue;
 }

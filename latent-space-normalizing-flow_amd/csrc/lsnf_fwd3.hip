@@ -46,6 +46,7 @@ struct Fwd3Args {
     unsigned long long* stamps;        // LSNF_STAMPS diagnostic build only: [waves & 2047][64] clock stamps
     int shape16;                       // 1: the v_mfma_f32_16x16x32_bf16 variant (panels3 then points at its operand order)
     const unsigned* guard;             // fp16x2 kernel: the plan's guard words ([0]: weights outside fp16's range), read only
+    int hdump_tiled;                   // h1 / h2 in the tiled form (lsnf_l16.h l16_store_tiled) instead of row-major
     float* hdump; int width;           // L16 kernels: NULL, or the parameter-gradient dump (LsnfDumpLayout): h1, h2 of every block
     int fixup;                         // bf16x3 L16 kernel: 1 = run as the fix-up pass of an fp16x2 launch: a workgroup
                                        // recomputes its rows only if one of its waves left LSNF_F16_SENTINEL_BITS in
@@ -454,7 +455,10 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3b_kernel(const Fwd3
         }
         if (a.hdump) {           // kernel-uniform: h1 for the batch contraction dW2' = h1^T g_a2 (lsnf_params.hip)
 #pragma unroll
-            for (int t = 0; t < WT; ++t) l16_store_plain(h1[t], a.hdump + (size_t)blk * dl.per_block + dl.off_h1, sample, live, a.width, t, g, w4);
+            for (int t = 0; t < WT; ++t) {
+                if (a.hdump_tiled) { if (wtile * 32 < (size_t)a.B) l16_store_tiled(h1[t], a.hdump + (size_t)blk * dl.per_block + dl.off_h1, wtile, a.width, t, n, g); }
+                else l16_store_plain(h1[t], a.hdump + (size_t)blk * dl.per_block + dl.off_h1, sample, live, a.width, t, g, w4);
+            }
         }
         // ---- S3: h2 = relu(actnorm(h1 @ W2))  (model.py:326-328,308) ----
         f32x16 h2[WT];
@@ -471,7 +475,10 @@ __global__ __launch_bounds__(64 * F3_WAVES, 1) void lsnf_fwd3b_kernel(const Fwd3
         }
         if (a.hdump) {
 #pragma unroll
-            for (int t = 0; t < WT; ++t) l16_store_plain(h2[t], a.hdump + (size_t)blk * dl.per_block + dl.off_h2, sample, live, a.width, t, g, w4);
+            for (int t = 0; t < WT; ++t) {
+                if (a.hdump_tiled) { if (wtile * 32 < (size_t)a.B) l16_store_tiled(h2[t], a.hdump + (size_t)blk * dl.per_block + dl.off_h2, wtile, a.width, t, n, g); }
+                else l16_store_plain(h2[t], a.hdump + (size_t)blk * dl.per_block + dl.off_h2, sample, live, a.width, t, g, w4);
+            }
         }
         // ---- S4: shift t / pre-sigmoid p = fc_zeros(h2), de-interleaved (model.py:347-349,411-413) ----
         f32x16 tp[2 * HT];
@@ -593,9 +600,10 @@ hipError_t launch_fwd3(const Fwd3Args& a, hipStream_t stream) {
 hipError_t LSNF_FWD3_ENTRY(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                 const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                 float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4,
-                                int shape16, int fixup, hipStream_t stream, float* hdump) {
+                                int shape16, int fixup, hipStream_t stream, float* hdump, int hdump_tiled) {
     Fwd3Args a;
     a.shape16 = shape16;
+    a.hdump_tiled = hdump_tiled;
     a.hdump = hdump ? hdump + (size_t)first_block * lsnf_dump_layout(B, g.nz, g.width).per_block : nullptr;
     a.width = g.width;
     if (hdump && !shape16) return hipErrorInvalidValue;      // (the dump is written by the L16 kernels)

@@ -175,6 +175,21 @@ __device__ __forceinline__ void l16_store_plain(const f32x16& x, float* __restri
             }
         }
 }
+// The same tile into the TILED form of a (B, ld) tensor (ld % 16 == 0): per 32-sample tile, 16-byte unit
+// ((fg >> 2) * 2 + (s >> 4)) * 64 + (s & 15) * 4 + (fg & 3) for feature group fg = feature / 4 and sample s -- one store instruction
+// (ft, st) writes 1 KiB of consecutive bytes (the row-major form: 16 rows x 64 bytes), and the batch contraction reads 256-byte runs
+// (lsnf_params3.hip).  The tile is written whole: rows past the batch hold what the lanes hold.
+__device__ __forceinline__ void l16_store_tiled(const f32x16& x, float* __restrict__ base, size_t tile32, int ld, int t, int n, int g) {
+    f32x4* p = reinterpret_cast<f32x4*>(base + tile32 * 32 * (size_t)ld);
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int b = (2 * ft + st) * 4;
+            f32x4 v = {x[b], x[b + 1], x[b + 2], x[b + 3]};
+            p[(((2 * t + ft) * 2 + st) * 16 + n) * 4 + g] = v;
+        }
+}
 // bias block of one n-tile ([h][r] order of the 32x32 layout, lsnf_prep.hip bias_feature) -> L16 accumulators
 __device__ __forceinline__ f32x16 l16_bias_init(const float* cst, int g) {
     f32x16 a;

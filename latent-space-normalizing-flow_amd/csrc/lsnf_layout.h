@@ -177,7 +177,8 @@ struct LsnfDumpLayout { size_t off_gv, off_ga1, off_ga2, off_gt, off_gp, off_h1,
 __host__ __device__
 #endif
 static inline LsnfDumpLayout lsnf_dump_layout(int B, int nz, int width) {
-    LsnfDumpLayout d; size_t o = 0; const size_t b = (size_t)B; const int half = nz / 2;
+    // (rows rounded up to whole 32-sample tiles: the tiled form of the large-batch path writes whole tiles, lsnf_l16.h l16_store_tiled)
+    LsnfDumpLayout d; size_t o = 0; const size_t b = ((size_t)B + 31) / 32 * 32; const int half = nz / 2;
     d.off_gv = o;  o = LSNF_AL4(o + b * nz);
     d.off_ga1 = o; o = LSNF_AL4(o + b * width);
     d.off_ga2 = o; o = LSNF_AL4(o + b * width);
@@ -202,9 +203,17 @@ static inline LsnfFoldLayout lsnf_fold_layout(int nz, int width) {
     f.per_block = (o + 3) & ~3;
     return f;
 }
-static inline size_t lsnf_params_workspace_floats(int nz, int width, int depth, int B) {
+// ... + 4 floats behind the dump: word 0 = the layout of the h1 / h2 arrays the forward of this evaluation wrote (0 row-major,
+// 1 tiled), set by lsnf_forward for the batch sizes at which the contraction of lsnf_params3.hip may run
+static inline size_t lsnf_params_workspace_tag(int nz, int width, int depth, int B) {
     return 4 + (size_t)depth * lsnf_fold_layout(nz, width).per_block + (size_t)depth * lsnf_dump_layout(B, nz, width).per_block;
 }
+static inline size_t lsnf_params_workspace_floats(int nz, int width, int depth, int B) {
+    return lsnf_params_workspace_tag(nz, width, depth, B) + 4;
+}
+// the tiled form of the dump needs whole feature groups of 16 and the natural tile order of the latent rows
+static inline int lsnf_dump_can_tile(int nz, int width) { return nz % 64 == 0 && width % 16 == 0; }
+#define LSNF_X3_MIN_ROWS 12288      /* lsnf_params3.hip takes the batch contraction from this many rows (fp32-MFMA kernel below) */
 
 // ---- optional activation stash of the forward (act_saved), read by the backward instead of recomputing the MLP ----
 // Opaque, register-order layout, per block and per 32-sample tile `wt` (nwt = ceil(B/32) tiles):

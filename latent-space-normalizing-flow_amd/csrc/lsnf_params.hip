@@ -40,11 +40,13 @@ hipError_t lsnf_launch_small3_backward_z(const LsnfGeo& g, const float* plan, in
 hipError_t lsnf_launch_backward3_z(const LsnfGeo& g, const float* plan, int B, const float* z_out, const float* z_saved,
                                    const float* act_saved, const float* g_z1, const float* g_logdet, int ll_mode, float ll_scale,
                                    float* g_z_in, int vec4, hipStream_t stream, const LsnfLangevinArgs* lv,
-                                   float* dump, float* gl_total);
+                                   float* dump, float* gl_total, int dump_tiled);
 
 // lsnf_params3.hip: the same contraction on the bf16 matrix pipe (large batches); hipErrorInvalidValue = not covered
 hipError_t lsnf_launch_contract_x3(const float* z_in, const float* z_out, const float* z_saved, const float* dump, float* fold,
-                                   int B, int nz, int half, int width, int depth, int chunk_override, hipStream_t stream);
+                                   int B, int nz, int half, int width, int depth, int chunk_override, int g_tiled, const int* h_tag,
+                                   hipStream_t stream);
+bool lsnf_contract_x3_covers(int B, int nz, int half, int width, const float* z_in, const float* z_out, const float* z_saved);
 
 namespace {
 
@@ -421,12 +423,18 @@ hipError_t lsnf_launch_backward_params(const LsnfGeo& g, const float* plan, cons
     // into this workspace's dump (lsnf_forward(params_workspace)); the backward FROM THE STASH, on the bf16 matrix pipe, adds
     // g_v, g_a1, g_a2, g_t, g_p -- no recomputation of the coupling MLP (1.0x instead of 1.5x the forward's matrix work, at
     // 2.6x the matrix rate).  Otherwise: the recomputing fp32-MFMA backward writes all seven tensors itself.
+    // Large batches on the fast path (bf16x3-family math: act_saved given): the contraction runs on the bf16 matrix pipe, operands read
+    // once (lsnf_params3.hip; LSNF_TN_X3=0 keeps the fp32-MFMA kernels), and the throughput backward then writes its g arrays in the
+    // tiled form (whole 1 KiB stores instead of 16 rows x 64 bytes; g_v as its first half only: the second half is g_t)
+    static const bool knob_plain = getenv("LSNF_TN_PLAIN") != nullptr;
+    const bool use_x3 = act_saved && lsnf_contract_x3_covers(B, g.nz, g.half, g.width, z_in, z_out, z_saved);
+    const int g_tiled = (use_x3 && !small_batch && lsnf_dump_can_tile(g.nz, g.width)) ? 1 : 0;
     if (act_saved) {
         e = small_batch
             ? lsnf_launch_small3_backward_z(g, plan, B, z_out, z_saved, act_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, vec4, stream,
                                             nullptr, dump, gl_total)
             : lsnf_launch_backward3_z(g, plan, B, z_out, z_saved, act_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, vec4, stream,
-                                      nullptr, dump, gl_total);
+                                      nullptr, dump, gl_total, g_tiled);
     } else
     e = small_batch
         ? lsnf_launch_small_backward_z(g, plan, B, z_out, z_saved, g_z1, g_logdet, ll_mode, ll_scale, g_z_in, vec4, stream,
@@ -440,16 +448,14 @@ hipError_t lsnf_launch_backward_params(const LsnfGeo& g, const float* plan, cons
     // experiment knobs of tools/tn_probe.py (read once per process): ablation switches, samples per workgroup, plain kernel
     static const int knob_abl = [] { const char* e = getenv("LSNF_TN_ABL"); return e ? atoi(e) : 0; }();
     static const int knob_chunk = [] { const char* e = getenv("LSNF_TN_CHUNK"); return e ? atoi(e) : 0; }();
-    static const bool knob_plain = getenv("LSNF_TN_PLAIN") != nullptr;
     t.abl = knob_abl;
     if (knob_chunk > 0) t.chunk = knob_chunk;
     const unsigned chunks = (unsigned)((B + t.chunk - 1) / t.chunk);
-    // Large batches on the fast path (bf16x3-family math: act_saved given): the contraction on the bf16 matrix pipe, operands read once
-    // (lsnf_params3.hip); LSNF_TN_X3=0 keeps the fp32-MFMA kernel below.
-    static const bool knob_x3 = [] { const char* e = getenv("LSNF_TN_X3"); return e ? atoi(e) != 0 : true; }();
     e = hipErrorInvalidValue;
-    if (act_saved && knob_x3 && !knob_plain && B >= 12288 && vec4 == 4)
-        e = lsnf_launch_contract_x3(z_in, z_out, z_saved, dump, fold, B, g.nz, g.half, g.width, g.depth, knob_chunk, stream);
+    if (use_x3)
+        e = lsnf_launch_contract_x3(z_in, z_out, z_saved, dump, fold, B, g.nz, g.half, g.width, g.depth, knob_chunk, g_tiled,
+                                    reinterpret_cast<const int*>(workspace + lsnf_params_workspace_tag(g.nz, g.width, g.depth, B)), stream);
+    if (e == hipErrorInvalidValue && g_tiled) return hipErrorUnknown;        // (cannot happen: lsnf_contract_x3_covers said yes)
     if (e == hipSuccess) {
     } else if (e != hipErrorInvalidValue) {
         return e;

@@ -39,11 +39,12 @@ constexpr int X3_LDS = 2 * X3_BUFFER;          // double-buffered: 122 880 bytes
 struct X3Args {
     const float* z_in; const float* z_out; const float* z_saved; const float* dump; float* fold;
     int B, nz, half, width, depth, chunk;
+    int g_tiled; const int* h_tag;     // the g arrays / (word read on the device) the h arrays in the tiled form of lsnf_l16.h l16_store_tiled
 };
 struct X3Task {
-    const float* A; int lda, K;
-    const float* G0; const float* G1; int ldg0, ldg1, N, nsplit;     // G columns [0, nsplit) from G0, [nsplit, N) from G1
-    float* C0; float* C1; float* cs0; float* cs1;                     // C0: K x nsplit, C1: K x (N - nsplit), row-major; column sums
+    const float* A; int lda, K, a_tiled;
+    const float* G0; const float* G1; int ldg0, ldg1, N, nsplit, g_tiled;   // G columns [0, nsplit) from G0, [nsplit, N) from G1
+    float* C0; float* C1; int ldc0, ldc1; float* cs0; float* cs1;     // columns [0, nsplit) of the result -> C0 (row stride ldc0), the rest -> C1; column sums
 };
 
 __device__ __forceinline__ unsigned x3_pk(float a, float b) {
@@ -55,19 +56,31 @@ __device__ __forceinline__ unsigned x3_pk(float a, float b) {
 // Its rows are read with raw BUFFER loads: no branch around a load (with conditional loads the compiler's wait-count bookkeeping
 // gave up at the loop head -- s_waitcnt vmcnt(0) in front of every split: no stage in flight), and the descriptor's extent returns
 // zeros for rows past the batch; a column group past the segment's width carries the offset 2^31 (always out of range).
-struct X3Segment { __amdgpu_buffer_rsrc_t rs; int ld, ncols, feat0; };
-__device__ __forceinline__ X3Segment x3_segment(const float* base, int col0, int ld, int ncols, int feat0, int B) {
+// Sample order inside a stage: thread (column group, rg) holds the samples rg + 4 j, j = 0..7, as its run of eight k indices -- for A
+// and G alike, so the order is immaterial to the products.  Row-major source: load j covers four consecutive rows x 256 bytes per
+// wave; tiled source (l16_store_tiled): 16-byte unit ((fg >> 2) * 8 + j) * 16 + rg * 4 + (fg & 3) of the 32-sample tile, again
+// 256-byte runs, and j * 256 bytes between a thread's loads.
+struct X3Segment { __amdgpu_buffer_rsrc_t rs; int ld, ncols, feat0, col0, tiled; };
+__device__ __forceinline__ X3Segment x3_segment(const float* base, int col0, int ld, int ncols, int feat0, int B, int tiled) {
     X3Segment g;
-    const long floats = ncols > 0 ? (long)B * ld - col0 : 0;
-    g.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) + (ncols > 0 ? col0 : 0), 0, (int)(floats * 4), 0x00020000);
-    g.ld = ld; g.ncols = ncols; g.feat0 = feat0;
+    const long rows = tiled ? ((long)B + 31) / 32 * 32 : (long)B;
+    const long floats = ncols > 0 ? rows * ld - (tiled ? 0 : col0) : 0;
+    g.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) + ((ncols > 0 && !tiled) ? col0 : 0), 0, (int)(floats * 4), 0x00020000);
+    g.ld = ld; g.ncols = ncols; g.feat0 = feat0; g.col0 = col0; g.tiled = tiled;
     return g;
 }
-// rows row .. row + 7 of this thread's 4-column group (voff: byte offset of (row, column group))
-__device__ __forceinline__ void x3_load(f32x4 (&r)[8], const X3Segment& g, unsigned voff) {
+// byte offset of this thread's first load of the stage that starts at row m0 (a multiple of 32), and between its loads
+__device__ __forceinline__ unsigned x3_voff(const X3Segment& g, int m0, int col, int rg) {
+    if (g.tiled) {
+        const int fg = (g.col0 + col) >> 2;
+        return (unsigned)(m0 * g.ld * 4 + (((fg >> 2) * 8) * 16 + rg * 4 + (fg & 3)) * 16);
+    }
+    return (unsigned)(((m0 + rg) * g.ld + col) * 4);
+}
+__device__ __forceinline__ void x3_load(f32x4 (&r)[8], const X3Segment& g, unsigned voff, unsigned jstride) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j)     // (the whole offset in the VGPR: the range check then does not depend on how the scalar offset enters it)
-        r[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g.rs, voff + (unsigned)(j * g.ld * 4), 0, 0));
+    for (int j = 0; j < 8; ++j)     // (the whole offset in the VGPR: the range check then does not depend on how a scalar offset would enter it)
+        r[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g.rs, voff + (unsigned)j * jstride, 0, 0));
 }
 // split the 8 samples x 4 features of this thread and write them as 3 x 4 sixteen-byte runs (8 consecutive samples of one feature)
 template <bool SUMS>
@@ -132,23 +145,23 @@ __device__ __forceinline__ void x3_task(const X3Task& t, int m_begin, int m_end,
         // Thread = (column group c4 = lane >> 2, row group rg = lane & 3): 8 rows x 4 columns per stage.
         const bool isg = wave >= 6, second = (wave & 1) != 0;
         X3Segment g;
-        if (!isg) g = second ? x3_segment(t.A, 64, t.lda, t.K - 64, 64, m_end_all) : x3_segment(t.A, 0, t.lda, min(t.K, 64), 0, m_end_all);
-        else if (t.G1 != nullptr) g = second ? x3_segment(t.G1, 0, t.ldg1, t.N - t.nsplit, t.nsplit, m_end_all) : x3_segment(t.G0, 0, t.ldg0, t.nsplit, 0, m_end_all);
-        else g = second ? x3_segment(t.G0, 64, t.ldg0, t.N - 64, 64, m_end_all) : x3_segment(t.G0, 0, t.ldg0, min(t.N, 64), 0, m_end_all);
+        if (!isg) g = second ? x3_segment(t.A, 64, t.lda, t.K - 64, 64, m_end_all, t.a_tiled) : x3_segment(t.A, 0, t.lda, min(t.K, 64), 0, m_end_all, t.a_tiled);
+        else if (t.G1 != nullptr) g = second ? x3_segment(t.G1, 0, t.ldg1, t.N - t.nsplit, t.nsplit, m_end_all, t.g_tiled) : x3_segment(t.G0, 0, t.ldg0, t.nsplit, 0, m_end_all, t.g_tiled);
+        else g = second ? x3_segment(t.G0, 64, t.ldg0, t.N - 64, 64, m_end_all, t.g_tiled) : x3_segment(t.G0, 0, t.ldg0, min(t.N, 64), 0, m_end_all, t.g_tiled);
         const int rg = lane & 3, col = 4 * (lane >> 2);
         const bool live = col < g.ncols;                               // (a dead column group writes nothing: those feature rows feed
         char* wr = lds + (isg ? X3_OPERAND : 0) + (g.feat0 + col) * X3_PITCH + rg * 16;   //  output tiles that the epilogue drops)
         float cs[4] = {0.f, 0.f, 0.f, 0.f};
         f32x4 r0[8], r1[8], r2[8];                                     // three stages of rows in flight
-        unsigned voff = live ? (unsigned)(((m_begin + 8 * rg) * g.ld + col) * 4) : 0x80000000u;
-        const unsigned step = (unsigned)(X3_S * g.ld * 4);
-        x3_load(r0, g, voff); voff += step;
-        x3_load(r1, g, voff); voff += step;
-        x3_load(r2, g, voff); voff += step;
+        unsigned voff = live ? x3_voff(g, m_begin, col, rg) : 0x80000000u;
+        const unsigned step = (unsigned)(X3_S * g.ld * 4), jstride = g.tiled ? 256u : (unsigned)(16 * g.ld);
+        x3_load(r0, g, voff, jstride); voff += step;
+        x3_load(r1, g, voff, jstride); voff += step;
+        x3_load(r2, g, voff, jstride); voff += step;
         auto stage = [&](f32x4 (&r)[8], int s) {                       // stage s: split + write into buffer s & 1, then fetch stage s + 3
             char* w = wr + (s & 1) * X3_BUFFER;
             if (live && (!(X3_ABL & 8) || s == 0)) { if (isg) x3_split_store<true>(r, w, cs); else x3_split_store<false>(r, w, cs); }
-            if (!(X3_ABL & 4)) { x3_load(r, g, voff); voff += step; }
+            if (!(X3_ABL & 4)) { x3_load(r, g, voff, jstride); voff += step; }
             __syncthreads();
         };
         for (int s = 0; s < ns; s += 3) {                              // (the conditions are workgroup-uniform)
@@ -181,7 +194,6 @@ __device__ __forceinline__ void x3_task(const X3Task& t, int m_begin, int m_end,
     __syncthreads();
     // results: acc[mi][nt][r] = dM[16*(wave + 4*mi) + 4*(lane >> 4) + r][16*nt + (lane & 15)]
     const int n0 = lane & 15, g = lane >> 4;
-    const int ldc0 = t.nsplit, ldc1 = t.N - t.nsplit;
 #pragma unroll
     for (int mi = 0; mi < MPW; ++mi)
 #pragma unroll
@@ -189,7 +201,7 @@ __device__ __forceinline__ void x3_task(const X3Task& t, int m_begin, int m_end,
             const int n = 16 * nt + n0;
             if (n < t.N) {
                 float* c = n < t.nsplit ? t.C0 + n : t.C1 + (n - t.nsplit);
-                const int ldc = n < t.nsplit ? ldc0 : ldc1;
+                const int ldc = n < t.nsplit ? t.ldc0 : t.ldc1;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int k = 16 * (wave + 4 * mi) + 4 * g + r;
@@ -215,23 +227,26 @@ __global__ __launch_bounds__(512, 1) void lsnf_contract_x3_kernel(const X3Args a
     float* fold = a.fold + (size_t)blk * fl.per_block;
     const float* yblk = (blk == a.depth - 1) ? a.z_out : a.z_saved + (size_t)blk * a.B * a.nz;
     const float* xblk = (blk == 0) ? a.z_in : a.z_saved + (size_t)(blk - 1) * a.B * a.nz;
+    const int h_tiled = *a.h_tag, gt_ = a.g_tiled;                     // (uniform)
     X3Task t;
-    // T0: dWa = x^T g_v
-    t.A = xblk; t.lda = a.nz; t.K = a.nz; t.G0 = dmp + dl.off_gv; t.G1 = nullptr; t.ldg0 = a.nz; t.ldg1 = 0; t.N = a.nz; t.nsplit = a.nz;
-    t.C0 = fold + fl.dWa; t.C1 = nullptr; t.cs0 = fold + fl.dca; t.cs1 = nullptr;
+    // T0: dWa = x^T g_v; tiled dump: g_v = [g_v1 (its own array, half columns) | g_t]
+    t.A = xblk; t.lda = a.nz; t.K = a.nz; t.a_tiled = 0; t.g_tiled = gt_; t.N = a.nz;
+    if (gt_) { t.G0 = dmp + dl.off_gv; t.G1 = dmp + dl.off_gt; t.ldg0 = a.half; t.ldg1 = a.half; t.nsplit = a.half; }
+    else { t.G0 = dmp + dl.off_gv; t.G1 = nullptr; t.ldg0 = a.nz; t.ldg1 = 0; t.nsplit = a.nz; }
+    t.C0 = fold + fl.dWa; t.C1 = fold + fl.dWa + t.nsplit; t.ldc0 = a.nz; t.ldc1 = a.nz; t.cs0 = fold + fl.dca; t.cs1 = fold + fl.dca + t.nsplit;
     x3_run(t, m_begin, m_end, a.B, x3_lds);
     // T1: dW1' = v1^T g_a1
-    t.A = yblk; t.lda = a.nz; t.K = a.half; t.G0 = dmp + dl.off_ga1; t.ldg0 = a.width; t.N = a.width; t.nsplit = a.width;
-    t.C0 = fold + fl.dW1; t.cs0 = fold + fl.dc1;
+    t.A = yblk; t.lda = a.nz; t.K = a.half; t.G0 = dmp + dl.off_ga1; t.G1 = nullptr; t.ldg0 = a.width; t.N = a.width; t.nsplit = a.width;
+    t.C0 = fold + fl.dW1; t.ldc0 = a.width; t.cs0 = fold + fl.dc1;
     x3_run(t, m_begin, m_end, a.B, x3_lds);
     // T2: dW2' = h1^T g_a2
-    t.A = dmp + dl.off_h1; t.lda = a.width; t.K = a.width; t.G0 = dmp + dl.off_ga2; t.ldg0 = a.width; t.N = a.width; t.nsplit = a.width;
-    t.C0 = fold + fl.dW2; t.cs0 = fold + fl.dc2;
+    t.A = dmp + dl.off_h1; t.lda = a.width; t.K = a.width; t.a_tiled = h_tiled; t.G0 = dmp + dl.off_ga2; t.ldg0 = a.width; t.N = a.width; t.nsplit = a.width;
+    t.C0 = fold + fl.dW2; t.ldc0 = a.width; t.cs0 = fold + fl.dc2;
     x3_run(t, m_begin, m_end, a.B, x3_lds);
     // T3: [dW3s | dW3p] = h2^T [g_t | g_p]
     t.A = dmp + dl.off_h2; t.lda = a.width; t.K = a.width; t.G0 = dmp + dl.off_gt; t.G1 = dmp + dl.off_gp; t.ldg0 = a.half; t.ldg1 = a.half;
     t.N = 2 * a.half; t.nsplit = a.half;
-    t.C0 = fold + fl.dW3s; t.C1 = fold + fl.dW3p; t.cs0 = fold + fl.dc3s; t.cs1 = fold + fl.dc3p;
+    t.C0 = fold + fl.dW3s; t.C1 = fold + fl.dW3p; t.ldc0 = a.half; t.ldc1 = a.half; t.cs0 = fold + fl.dc3s; t.cs1 = fold + fl.dc3p;
     x3_run(t, m_begin, m_end, a.B, x3_lds);
 }
 
@@ -246,10 +261,21 @@ hipError_t x3_allow_lds(const void* kern) {
 
 // hipErrorInvalidValue = not covered (the caller runs the fp32-MFMA contraction of lsnf_params.hip): rows that do not take 16-byte
 // loads, operands wider than 128 features.  (all rows 16-byte aligned: the caller checked the tensors and nz, width, half % 4 == 0)
+// Does this kernel take the contraction of such a call?  ONE rule for lsnf_forward (which then may write h1 / h2 tiled) and for
+// lsnf_backward_params: batch size, geometry (operands of <= 128 features in whole 16-byte groups, 32-bit byte offsets), the three
+// latent tensors 16-byte aligned, and the process-wide knobs LSNF_TN_X3=0 / LSNF_TN_PLAIN (fp32-MFMA kernels of lsnf_params.hip).
+bool lsnf_contract_x3_covers(int B, int nz, int half, int width, const float* z_in, const float* z_out, const float* z_saved) {
+    static const bool knob = [] { const char* e = getenv("LSNF_TN_X3"); return (e ? atoi(e) != 0 : true) && getenv("LSNF_TN_PLAIN") == nullptr; }();
+    if (!knob || B < LSNF_X3_MIN_ROWS) return false;
+    if (nz > 128 || width > 128 || 2 * half > 128 || (nz & 3) || (width & 3) || (half & 3) || ((size_t)B + 32) * 128 * 4 >= (1ull << 31)) return false;
+    return (((size_t)z_in | (size_t)z_out | (size_t)z_saved) & 15) == 0;
+}
 hipError_t lsnf_launch_contract_x3(const float* z_in, const float* z_out, const float* z_saved, const float* dump, float* fold,
-                                   int B, int nz, int half, int width, int depth, int chunk_override, hipStream_t stream) {
-    if (nz > 128 || width > 128 || 2 * half > 128 || (nz & 3) || (width & 3) || (half & 3) || (size_t)B * 128 * 4 >= (1ull << 31)) return hipErrorInvalidValue;
+                                   int B, int nz, int half, int width, int depth, int chunk_override, int g_tiled, const int* h_tag,
+                                   hipStream_t stream) {
+    if (!lsnf_contract_x3_covers(B, nz, half, width, z_in, z_out, z_saved)) return hipErrorInvalidValue;
     X3Args a;
+    a.g_tiled = g_tiled; a.h_tag = h_tag;
     a.z_in = z_in; a.z_out = z_out; a.z_saved = z_saved; a.dump = dump; a.fold = fold;
     a.B = B; a.nz = nz; a.half = half; a.width = width; a.depth = depth;
     // one round of workgroups: ~256 / depth chunks of the batch, in whole stages
