@@ -32,13 +32,17 @@ def trace(key, B):
 # op -> (dominant kernel by size, algorithmic FLOP / sample, algorithmic HBM bytes / sample, pipe)
 TABLE = {
     "reverse": ({100: "lsnf_small3_rev_kernel", 65536: "lsnf_rev3_kernel"}, F, 8 * NZ + 8, "bf16"),
+    # the stash-writing instantiation of the pipelined forward (template flag true): + block outputs + stash
+    "forward + stash (pipelined)": ({100: "lsnf_small3_fwd_kernel", 65536: "lsnf_fwd3q_kernel&true>"}, F, 8 * NZ + 8 + (D - 1) * 4 * NZ + D * STASH, "bf16"),
     # (kernel names carry the template flags: "false>" = no parameter-gradient dump; the Langevin update runs the same kernel)
     "backward_z_from_stash (+ Langevin update)": ({100: "lsnf_small3_bwd_kernel&false>", 65536: "lsnf_bwd3_kernel&false>"}, F, 4 * NZ * 2 + D * (2 * NZ + STASH), "bf16"),
-    "backward_from_stash + g dump": ({100: "lsnf_small3_bwd_kernel&true>", 65536: "lsnf_bwd3_kernel&true>"}, F, 4 * NZ * 2 + D * (2 * NZ + STASH) + D * 4 * (NZ + 2 * W + 2 * (NZ // 2)), "bf16"),
+    # (65 536 rows: tiled dump, g_v as its first half only)
+    "backward_from_stash + g dump": ({100: "lsnf_small3_bwd_kernel&true>", 65536: "lsnf_bwd3_kernel&true>"}, F, 4 * NZ * 2 + D * (2 * NZ + STASH) + D * 4 * (NZ // 2 + 2 * W + 2 * (NZ // 2)), "bf16"),
     # (one kernel serves forward / + stash / + h dump: the median is over the driver's mix of the three)
-    "forward (mix: plain, + stash, + h dump)": ({100: "lsnf_small3_fwd_kernel", 65536: "lsnf_fwd3b_kernel"}, F, 8 * NZ + 8 + (D - 1) * 4 * NZ + D * STASH, "bf16"),
+    "forward + stash + h dump (65 536 rows: the phase-separated kernel; 100 rows: the latency kernel's mix of the three forms)": ({100: "lsnf_small3_fwd_kernel", 65536: "lsnf_fwd3b_kernel"}, F, 8 * NZ + 8 + (D - 1) * 4 * NZ + D * STASH + D * 8 * W, "bf16"),
     "restash": ({100: "lsnf_small3_restash_kernel", 65536: "lsnf_small3_restash_kernel"}, D * 2 * (NZ // 2 * W + W * W + W * NZ // 2), D * (2 * NZ + STASH), "bf16"),
-    "batch_contraction": ({100: "lsnf_tn_gemm_kernel", 65536: "lsnf_tn_gemm_lds_kernel"}, F, D * 4 * (2 * NZ + NZ // 2 + 5 * W + 2 * (NZ // 2) + W), "fp32"),
+    # (65 536 rows: lsnf_params3.hip on the bf16 pipe, h2 read once; 100 rows: the fp32-MFMA kernel, h2 read per task)
+    "batch_contraction": ({100: "lsnf_tn_gemm_kernel", 65536: "lsnf_contract_x3_kernel"}, F, D * 4 * (2 * NZ + NZ // 2 + 4 * W + 2 * (NZ // 2) + NZ // 2), "bf16 (65536) / fp32 (100)"),
     "unfold": ({100: "lsnf_unfold_kernel", 65536: "lsnf_unfold_kernel"}, 0, 0, "fp64 vector"),
 }
 out = {"geometry": "C3: nz=128 f_width=64 f_depth=5, default arithmetic bf16x3", "flop_per_sample_one_pass": F,
@@ -59,8 +63,9 @@ for op, (kern, flop, byts, pipe) in TABLE.items():
         if flop:
             tf = flop * B / med / 1e6
             e["alg_tflops"] = tf
-            e["frac_pipe"] = tf / (PEAK_BF16 if pipe == "bf16" else PEAK_FP32)
-            e["pipe"] = pipe + " MFMA"
+            on_bf16 = pipe == "bf16" or (pipe.startswith("bf16 (65536)") and B == 65536)
+            e["frac_pipe"] = tf / (PEAK_BF16 if on_bf16 else PEAK_FP32)
+            e["pipe"] = ("bf16" if on_bf16 else "fp32") + " MFMA"
         if byts:
             e["alg_gbs"] = byts * B / med / 1e3
             e["frac_hbm"] = e["alg_gbs"] / PEAK_HBM
