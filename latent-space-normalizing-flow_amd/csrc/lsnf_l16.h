@@ -185,6 +185,7 @@ __device__ __forceinline__ void l16_store_tiled(const f32x16& x, float* __restri
     for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
+            if (32 * t + 16 * ft >= ld) continue;          // (a padded half of the last feature tile: past the tile's bytes)
             const int b = (2 * ft + st) * 4;
             f32x4 v = {x[b], x[b + 1], x[b + 2], x[b + 3]};
             p[(((2 * t + ft) * 2 + st) * 16 + n) * 4 + g] = v;

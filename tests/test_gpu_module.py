@@ -2,6 +2,8 @@
 C ABI, against the reference's golden vectors; plus the flow-MLE step (train.py:404-415) with Adam."""
 import types
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -202,39 +204,23 @@ def test_parameter_update_between_forward_and_backward_raises_on_device(lsnf, gp
     assert torch.isfinite(g_first).all()
 
 
-def test_generator_mirror_on_device_matches_reference_golden(lsnf, gpu_device):
+def test_generator_mirror_on_device_matches_reference_golden(gpu_device):
     """SURVEY 8f rank 4 on the GPU: `lsnf_amd._netG` (stock PyTorch-ROCm / MIOpen, tuned with channels-last + find mode)
     and `netg.langevin_grad_g` (train.py:312-314) against the reference's `_netG` golden vectors, every dataset variant --
-    the generator half of the Langevin step as it runs in examples/train_synthetic.py, not only its CPU mirror."""
-    import os
-    from conftest import ROOT
-    from lsnf_amd import netg
-    raw = np.load(os.path.join(ROOT, "tests", "golden", "netg_variants.npz"), allow_pickle=False)
-    tags = sorted({k.split("/")[0] for k in raw.files})
-    assert len(tags) == 5
-    for tuned in (False, True):
-        for tag in tags:
-            ds, act, bn = tag.rsplit("_", 2)
-            size, nz, ngf, B, sub = (int(v) for v in raw[f"{tag}/meta"])
-            args = types.SimpleNamespace(dataset=ds, nz=nz, ngf=ngf, nc=3, g_activation=act, g_activation_leak=0.2,
-                                         g_batchnorm=bn == "bn1")
-            net = netg._netG(args).eval()
-            net.load_state_dict({k[len(tag) + 4:]: torch.from_numpy(raw[k]) for k in raw.files if k.startswith(tag + "/sd/")},
-                                strict=True)
-            net = net.to(gpu_device)
-            if tuned:
-                net.tune()
-            z = torch.from_numpy(raw[f"{tag}/z"]).to(gpu_device)
-            b, c, i, j = np.meshgrid(np.arange(B), np.arange(3), np.arange(size), np.arange(size), indexing="ij")
-            x = torch.from_numpy(np.tanh(np.sin(0.37 * i + 0.91 * j + 1.7 * c + 2.3 * b)).astype(np.float32)).to(gpu_device)
-            with torch.no_grad():
-                x_hat = net(z)
-            assert (x_hat[:, :, ::sub, ::sub].cpu() - torch.from_numpy(raw[f"{tag}/x_hat"])).abs().max().item() <= 2e-5, tag
-            zg, gl = netg.langevin_grad_g(net, z, x, 0.3)
-            ref = torch.from_numpy(raw[f"{tag}/z_grad_g"])
-            assert abs(gl.item() - float(raw[f"{tag}/g_log_lkhd"])) <= 2e-5 * abs(float(raw[f"{tag}/g_log_lkhd"])), tag
-            assert (zg.cpu() - ref).norm().item() <= 2e-4 * ref.norm().item(), tag
-    torch.backends.cudnn.benchmark = False
+    the generator half of the Langevin step as it runs in examples/train_synthetic.py, not only its CPU mirror.
+    Runs in a FRESH child process (tests/generator_mirror_worker.py): MIOpen's find mode on the 256x256 variant launches a
+    solver that faults or not depending on what else the process has allocated on the card (found in round 3: the same test,
+    same MIOpen calls, aborted inside `conv_transpose2d` after the flow tests of a library build with slightly larger
+    workspaces and passed after those of the previous build; with `AMD_SERIALIZE_KERNEL=3` the abort stayed at that call, so
+    the faulting kernel is launched there, not by this repo's code).  The generator is stock MIOpen and out of the hot path;
+    what this test pins is the mirror's numerics."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, os.path.join(here, "generator_mirror_worker.py")], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-4000:]
+    assert "generator_mirror_ok 10" in p.stdout, p.stdout[-4000:]
 
 
 def test_parameter_gradients_run_to_run_spread_full_size(lsnf, gpu_device):
@@ -265,13 +251,18 @@ def test_parameter_gradients_run_to_run_spread_full_size(lsnf, gpu_device):
 
 
 @pytest.mark.parametrize("nz,width,B", [(128, 64, 100), (128, 64, 5000), (100, 64, 4500), (50, 33, 4100), (100, 128, 4200),
-                                         (128, 64, 14000), (128, 64, 40000), (128, 64, 65536)])
+                                         (128, 64, 14000), (128, 64, 40000), (128, 64, 65536),
+                                         (128, 64, 40001), (128, 48, 20000), (104, 64, 20000), (100, 64, 20000), (64, 32, 17000)])
 def test_parameter_gradients_from_the_stash_match_the_recomputing_path(lsnf, gpu_device, nz, width, B):
     """`lsnf_backward_params` fast path (forward keeps the activation stash and writes h1 / h2 into the workspace; the
     backward runs from the stash on the bf16 matrix pipe: latency kernels at B <= 16 384, throughput kernels above) against
     the recomputing fp32-MFMA path on the same inputs -- all 60 tensors and dL/dz; and against the float64 oracle on a
     whole batch at the sizes where that is affordable (these also cover the LDS-staged batch contraction of lsnf_params.hip,
-    used from 4 096 rows, in its three row-vector widths: nz/width/half multiples of 4, of 2, odd)."""
+    used from 4 096 rows, in its three row-vector widths: nz/width/half multiples of 4, of 2, odd; from 12 288 rows the contraction on
+    the bf16 matrix pipe, lsnf_params3.hip -- with the row-major dump of the latency family (14 000 rows), with the tiled dump of the
+    throughput family (whole tiles: 40 000, 65 536; a ragged last tile whose dead rows must read as zeros: 40 001; f_width 48, nz 64),
+    row-major above the threshold where the geometry does not tile (nz = 104: the two-source G operand split at column 52), and the
+    fp32 kernel where the bf16 one does not cover the rows (nz = 100: half = 50 is not a whole number of 16-byte groups))."""
     depth = 5
     p = O.init_params(nz, width, depth, seed=3)
     params = lsnf.params_from_state_dict(p, depth, gpu_device)
@@ -286,9 +277,18 @@ def test_parameter_gradients_from_the_stash_match_the_recomputing_path(lsnf, gpu
     z1b, _, _, savedb = lsnf.forward(plan, z, want_ll=False, save_for_backward=True)
     assert torch.equal(z1, z1b)
     slow, gz_slow = lsnf.backward_params(plan, params, z, z1b, savedb, ll_scale=-1.0 / B, want_grad_z=True)
+    # (the stash holds the ReLU masks of the forward's bf16x3 arithmetic, the recomputing path takes them from its own fp32 recompute:
+    #  among tens of thousands of rows one pre-activation may sit within rounding of its kink and flip -- one sample's contribution to
+    #  the gradients of that block's MLP, ~1e-4 of the tensor, identical for every contraction kernel (measured with LSNF_TN_X3=0 too):
+    #  the MLP tensors of at most two blocks are tolerated)
+    kinked = []
     for k, (a, b) in enumerate(zip(fast, slow)):
         assert torch.isfinite(a).all()
-        assert (a - b).norm().item() <= 2e-5 * max(b.norm().item(), 1e-12), (k, lsnf.flow.BLOCK_PARAM_KEYS[k % 12])
+        rel = (a - b).norm().item() / max(b.norm().item(), 1e-12)
+        assert rel <= 1e-3, (k, lsnf.flow.BLOCK_PARAM_KEYS[k % 12], rel)
+        if rel > 2e-5:
+            kinked.append((k, lsnf.flow.BLOCK_PARAM_KEYS[k % 12], rel))
+    assert len({k // 12 for k, _, _ in kinked}) <= (2 if B > 10000 else 0), kinked
     ok = (O.relu_margin(p, z.cpu()) > KINK).to(gpu_device)
     assert (gz_fast - gz_slow)[ok].norm().item() <= 1e-5 * gz_slow[ok].norm().item()
     if B <= 6000:
