@@ -556,7 +556,7 @@ __device__ __forceinline__ void stash_row_quad(const StashRsrc& rs, const StashL
     const int ft = q >> 1, st = q & 1, hh = t / HT, tt = t % HT;
     unsigned off = sl.zoff;
     if (st) off += (unsigned)(16 * nz * 4);
-    if (tt > 0) off = (32 * tt + 16 * ft + 4 * g < half) ? off : 0x80000000u;
+    off = (32 * tt + 16 * ft + 4 * g < half) ? off : 0x80000000u;        // (nz <= 64 runs on this HT = 2 kernel too: half < 32 pads tile 0 as well)
     // (the whole vector is cast: __builtin_bit_cast of ONE element of an ext_vector lvalue reads element 0 with this compiler)
     const u32x4s v = __builtin_bit_cast(u32x4s, x.q[q]);
     __builtin_amdgcn_raw_buffer_store_b128(v, rs.r[hh], off + (unsigned)((32 * tt + 16 * ft) * 4), 0, LSNF_STASH_AUX);

@@ -377,13 +377,15 @@ def test_split_bf16_dynamic_range(lsnf, gpu_device, z_scale, w_scale):
     assert err["fp16x2"] <= 3.0 * err["fp32"] + 1e-7, err
 
 
-@pytest.mark.parametrize("nz,width,depth,B", [(128, 64, 5, 40001), (104, 48, 3, 33000), (128, 64, 1, 32800), (128, 64, 2, 70001)])
+@pytest.mark.parametrize("nz,width,depth,B", [(128, 64, 5, 40001), (104, 48, 3, 33000), (128, 64, 1, 32800), (128, 64, 2, 70001),
+                                               (40, 33, 2, 32800), (8, 64, 3, 20000), (32, 64, 4, 32769)])
 def test_pipelined_forward_writes_the_phase_separated_stash(lsnf, gpu_device, nz, width, depth, B):
     """The stash-writing instantiation of the software-pipelined forward (lsnf_fwd3q_kernel<.., STASH>: buffer stores inside the
     MFMA phases, left in flight across the phase barriers) against the phase-separated kernel (math mode BF16X3_PHASED) on the
     same inputs: block outputs, sigma tiles and ReLU mask words bit for bit (what the backward reads does not depend on which
     forward wrote it), with every combination of the two optional buffers, ragged batches (waves and rows past the batch: their
-    stores are dropped by the buffer descriptors) and a padded second feature tile (nz = 104)."""
+    stores are dropped by the buffer descriptors), a padded second feature tile (nz = 104) and nz <= 64, where the first tile is
+    padded too (the randomised sweep found the row stores of those geometries unguarded in this kernel's first version)."""
     F = lsnf.flow
     p = O.init_params(nz, width, depth, seed=11)
     plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
