@@ -303,3 +303,28 @@ def test_parameter_gradients_from_the_stash_match_the_recomputing_path(lsnf, gpu
     again = lsnf.backward_params(plan, params, z, z1, saved, ll_scale=-1.0 / B, act_saved=act, workspace=ws)
     for a, b in zip(fast, again):
         assert (a - b).norm().item() <= 2e-6 * max(a.norm().item(), 1e-12)
+
+
+@pytest.mark.parametrize("mode", ["BF16X3_PHASED", "FP16X2"])
+def test_parameter_gradients_fast_path_large_batch_other_modes(lsnf, gpu_device, mode):
+    """The large-batch fast path in the other bf16x3-family modes: the phase-separated forward (tiled h dump, tag 1) and the fp16x2
+    forward (row-major h dump, tag 0) in front of the same backward (tiled g arrays) and bf16x3 contraction -- the contraction reads
+    the tag the forward left in the workspace."""
+    F = lsnf.flow
+    nz, width, depth, B = 128, 64, 5, 20000
+    p = O.init_params(nz, width, depth, seed=3)
+    params = lsnf.params_from_state_dict(p, depth, gpu_device)
+    plan = lsnf.prepare(params, nz, width, depth)
+    z = torch.randn(B, nz, generator=torch.Generator().manual_seed(B)).to(gpu_device)
+    prev = F.set_math_mode(getattr(F, "MATH_" + mode))
+    try:
+        act = F.new_act_saved(plan, B, gpu_device); act.fill_(float("nan"))
+        ws = F.new_params_workspace(plan, B, gpu_device); ws.fill_(float("nan"))
+        z1, _, _, saved = lsnf.forward(plan, z, want_ll=False, save_for_backward=True, act_saved=act, params_ws=ws)
+        fast = [g.clone() for g in lsnf.backward_params(plan, params, z, z1, saved, ll_scale=-1.0 / B, act_saved=act, workspace=ws)]
+        slow = lsnf.backward_params(plan, params, z, z1, saved, ll_scale=-1.0 / B)
+        for k, (a, b) in enumerate(zip(fast, slow)):
+            assert torch.isfinite(a).all()
+            assert (a - b).norm().item() <= 1e-3 * max(b.norm().item(), 1e-12), (k, F.BLOCK_PARAM_KEYS[k % 12])
+    finally:
+        F.set_math_mode(prev)
