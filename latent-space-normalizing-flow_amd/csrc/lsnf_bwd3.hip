@@ -62,7 +62,7 @@ __device__ __forceinline__ unsigned l16_load_mask(const unsigned* words, int n, 
     return m;
 }
 
-template <class C, int NW, bool DUMP>
+template <class C, int NW, int DUMP>       // DUMP: 0 none, 1 parameter-gradient dump row-major, 2 tiled (lsnf_l16.h l16_store_tiled)
 __global__ __launch_bounds__(64 * NW, 1) void lsnf_bwd3_kernel(const Bwd3Args a) {
     constexpr int HT = C::HT, WT = C::WT, NZT = C::NZT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -105,17 +105,22 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_bwd3_kernel(const Bwd3Args a)
     auto zero = [](int) { return lsnf_zero16(); };
     auto keep = [](f32x16 acc, int) { return acc; };
     const LsnfDumpLayout dl = lsnf_dump_layout(a.B, a.nz, a.width);
-    // tiled dump: this wave's 32-sample tile (not the clamped one: a wave past the batch stores nothing); rows past the batch inside
-    // the last tile are written as zeros (they are inside the arrays and the contraction sums whole tiles)
+    // tiled dump: this wave's 32-sample tile (not the clamped one: a wave past the batch stores nothing).  Rows past the batch inside
+    // the last tile must read as zeros (they are inside the arrays and the contraction sums whole tiles): the upstream gradient of a
+    // dead row is zeroed below, and every dumped quantity is linear in it.
     const size_t tile32 = (size_t)blockIdx.x * NW + wave;
-    const bool tile_ok = tile32 * 32 < (size_t)a.B, all_live = live[0] && live[1];
-    auto dead_rows_zero = [&](const f32x16& x) {
-        if (__builtin_amdgcn_ballot_w64(!all_live) == 0) return x;         // (wave-uniform: every tile but the batch's last)
-        f32x16 y = x;
+    const bool tile_ok = tile32 * 32 < (size_t)a.B;
+    if constexpr (DUMP == 2) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) y[r] = live[(r >> 2) & 1] ? x[r] : 0.0f;
-        return y;
-    };
+        for (int st = 0; st < 2; ++st) {
+            if (!live[st]) gl[st] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < NZT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (((r >> 2) & 1) == st && !live[st]) gx[t][r] = 0.0f;
+        }
+    }
     const bool w4 = (a.width & 3) == 0, h4 = (a.half & 3) == 0;
     if constexpr (DUMP) {   // G = sum_b dL/dlogdet_b: one atomic per wave
         float t = 0.0f;
@@ -153,8 +158,8 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_bwd3_kernel(const Bwd3Args a)
         if constexpr (DUMP) {
 #pragma unroll
             for (int t = 0; t < HT; ++t) {
-                if (a.dump_tiled) {
-                    if (tile_ok) { l16_store_tiled(dead_rows_zero(tp[t]), dmp + dl.off_gt, tile32, a.half, t, n, g); l16_store_tiled(dead_rows_zero(tp[HT + t]), dmp + dl.off_gp, tile32, a.half, t, n, g); }
+                if constexpr (DUMP == 2) {
+                    if (tile_ok) { l16_store_tiled(tp[t], dmp + dl.off_gt, tile32, a.half, t, n, g); l16_store_tiled(tp[HT + t], dmp + dl.off_gp, tile32, a.half, t, n, g); }
                 } else {
                     l16_store_plain(tp[t], dmp + dl.off_gt, sample, live, a.half, t, g, h4);
                     l16_store_plain(tp[HT + t], dmp + dl.off_gp, sample, live, a.half, t, g, h4);
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_bwd3_kernel(const Bwd3Args a)
         if constexpr (DUMP) {
 #pragma unroll
             for (int t = 0; t < WT; ++t) {
-                if (a.dump_tiled) { if (tile_ok) l16_store_tiled(dead_rows_zero(gh2[t]), dmp + dl.off_ga2, tile32, a.width, t, n, g); }
+                if constexpr (DUMP == 2) { if (tile_ok) l16_store_tiled(gh2[t], dmp + dl.off_ga2, tile32, a.width, t, n, g); }
                 else l16_store_plain(gh2[t], dmp + dl.off_ga2, sample, live, a.width, t, g, w4);
             }
         }
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_bwd3_kernel(const Bwd3Args a)
         if constexpr (DUMP) {
 #pragma unroll
             for (int t = 0; t < WT; ++t) {
-                if (a.dump_tiled) { if (tile_ok) l16_store_tiled(dead_rows_zero(gh1[t]), dmp + dl.off_ga1, tile32, a.width, t, n, g); }
+                if constexpr (DUMP == 2) { if (tile_ok) l16_store_tiled(gh1[t], dmp + dl.off_ga1, tile32, a.width, t, n, g); }
                 else l16_store_plain(gh1[t], dmp + dl.off_ga1, sample, live, a.width, t, g, w4);
             }
         }
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_bwd3_kernel(const Bwd3Args a)
 #pragma unroll
             for (int t = 0; t < NZT; ++t) {
                 // (tiled: g_v1 only, as a (B, half) array -- the second half IS g_t, which the contraction reads from its own array)
-                if (a.dump_tiled) { if (t < HT && tile_ok) l16_store_tiled(dead_rows_zero(gv[t]), dmp + dl.off_gv, tile32, a.half, t, n, g); }
+                if constexpr (DUMP == 2) { if (t < HT && tile_ok) l16_store_tiled(gv[t], dmp + dl.off_gv, tile32, a.half, t, n, g); }
                 else l16_store_tile<HT>(t, gv[t], dmp + dl.off_gv, sample, live, a.nz, a.half, g, vec4);
             }
         }
@@ -282,9 +287,9 @@ __global__ __launch_bounds__(64 * NW, 1) void lsnf_bwd3_kernel(const Bwd3Args a)
 template <class C, int NW>
 hipError_t launch_bwd3_w(const Bwd3Args& a, hipStream_t stream) {
     const size_t lds = 2 * (size_t)C::SLOT3 * sizeof(float);
-    auto kern = a.dump ? lsnf_bwd3_kernel<C, NW, true> : lsnf_bwd3_kernel<C, NW, false>;
-    static unsigned long long lds_ok[2] = {0, 0};
-    if (hipError_t e = lsnf_allow_big_lds((const void*)kern, &lds_ok[a.dump ? 1 : 0]); e != hipSuccess) return e;
+    auto kern = a.dump ? (a.dump_tiled ? lsnf_bwd3_kernel<C, NW, 2> : lsnf_bwd3_kernel<C, NW, 1>) : lsnf_bwd3_kernel<C, NW, 0>;
+    static unsigned long long lds_ok[3] = {0, 0, 0};
+    if (hipError_t e = lsnf_allow_big_lds((const void*)kern, &lds_ok[a.dump ? (a.dump_tiled ? 2 : 1) : 0]); e != hipSuccess) return e;
     const unsigned grid = (unsigned)((a.B + 32 * NW - 1) / (32 * NW));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, a);
     return hipGetLastError();
