@@ -17,7 +17,7 @@ reference's fp32 matmuls (model.py:187,326,347).  `--math fp32` runs the fp32-MF
 terms, 22 bits) is an opt-in mode and never the headline.
 
 N > 1: the headline is STRONG scaling -- the 65 536 rows of one evaluation sharded contiguously
-over the ranks (`parallel.shard_bounds`), one all-reduce per evaluation -- and the same run also times WEAK scaling
+over the ranks (`parallel.shard_bounds`), every evaluation all-reduced, `--strong-bucket` (8) evaluations per asynchronous collective -- and the same run also times WEAK scaling
 (65 536 rows per GPU, `--weak-bucket` evaluations per collective) and reports it as `weak_scaling`.
 
 Spread ("median and p10/p90"): the K-step timed region is repeated R = max(5, ceil(200 / K)) times behind ONE
@@ -254,6 +254,11 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: which form is the headline `value` (the other one is timed too and reported beside it)")
     ap.add_argument("--weak-bucket", type=int, default=32, help="evaluations per collective of the weak-scaling figure")
+    ap.add_argument("--strong-bucket", type=int, default=8,
+                    help="N > 1: evaluations per collective of the strong-scaling headline.  Every evaluation's [sum ll, sum logdet, rows] is "
+                         "all-reduced; the pipelined reducer sends the sums of this many consecutive evaluations in ONE asynchronous collective "
+                         "(the evaluations are independent, the sums are a few bytes).  With one collective per evaluation (1) the eager step "
+                         "costs ~47 us of host time per rank against a ~20 us shard kernel at 8 GPUs (DESIGN.md section 6): host-bound")
     ap.add_argument("--shard-of", type=int, default=0, metavar="N",
                     help="one GPU: time the shard of an N-GPU strong-scaling job (65 536 / N rows per step, same protocol) and "
                          "print the N-GPU ceiling it implies; the full-size step is timed in the same run")
@@ -316,7 +321,9 @@ def main():
         rows = z.shape[0]
         outs = [(torch.empty_like(z), torch.empty(rows, device=dev), torch.empty(rows, device=dev)) for _ in streams]
         reducers = [parallel.PipelinedStatsReducer(dev, bucket=bucket) for _ in streams]
-        return z, outs, reducers, streams
+        # (the launch of a step with its buffers bound and checked once: ~4 us of host time per call instead of ~12)
+        calls = [lsnf_amd.flow.BoundForward(plan, z, o) for o in outs]
+        return z, outs, reducers, streams, calls
 
     reps = args.reps if args.reps > 0 else max(5, -(-200 // max(1, args.steps)))
     graph_used = []
@@ -324,7 +331,7 @@ def main():
     def timed(run, steps, warmup):
         """clock ramp (untimed, not steps) + W untimed steps, then `reps` x (K timed steps); returns the list of seconds per
         K-step region (max over ranks each)."""
-        z, outs, reducers, streams = run
+        z, outs, reducers, streams, calls = run
         counter = [0]
 
         def step():
@@ -334,7 +341,7 @@ def main():
             counter[0] += 1
             with torch.cuda.stream(streams[k]):
                 stats = reducers[k].next_buffer()
-                lsnf_amd.forward(plan, z, out=outs[k], stats=stats)
+                calls[k](stats)                     # == lsnf_amd.forward(plan, z, out=outs[k], stats=stats)
                 reducers[k].submit(stats)
 
         # Clock ramp: MI355X needs ~50 ms of sustained load before it holds its steady shader clock (2.07 GHz in the first
@@ -442,7 +449,9 @@ def main():
     runs = {}
     for form in forms:
         z = z_strong if form == "strong" else z_weak
-        bucket = 1 if form != "weak" else max(1, args.weak_bucket)
+        bucket = max(1, args.strong_bucket) if form != "weak" else max(1, args.weak_bucket)
+        if world == 1:
+            bucket = 1                                                         # (one GPU: no collective, the reducer only rotates its banks)
         runs[form] = (make_run(z, bucket, side_streams if n_streams > 1 else [main_stream]), make_run(z, bucket, [main_stream]), bucket)
     torch.cuda.synchronize()
 

@@ -187,6 +187,34 @@ def forward(plan: FlowPlan, z: torch.Tensor, objective: Optional[torch.Tensor] =
     return z_out, logdet, ll, saved
 
 
+class BoundForward:
+    """`forward(plan, z, out=..., stats=...)` with everything but the `stats` row bound and checked ONCE: a call is then one ctypes
+    call on the current stream (~4 us of host time instead of ~12: tensor checks, size queries and pointer extraction are what a
+    20 us strong-scaling shard launch cannot afford per step, tools/host_cost_allreduce.py).  Same launch, same results.
+
+        fw = BoundForward(plan, z, out)          # buffers as for forward(); the plan is re-read at every call (data_ptr is stable)
+        fw(stats_row)                            # == forward(plan, z, out=out, stats=stats_row)
+    The caller keeps z / out / the plan alive and on the device that is current at call time."""
+
+    def __init__(self, plan: FlowPlan, z: torch.Tensor, out, objective: Optional[torch.Tensor] = None, act_saved: Optional[torch.Tensor] = None,
+                 z_saved_out: Optional[torch.Tensor] = None):
+        probe = new_stats(z.device)
+        forward(plan, z, objective, out=out, stats=probe, act_saved=act_saved, z_saved_out=z_saved_out)       # every check of forward(), once
+        self._keep = (plan, z, out, objective, act_saved, z_saved_out)
+        self._lib = _lib.load()
+        self._dev = z.device
+        B = z.shape[0]
+        self._head = (_ptr(plan.buf), plan.nz, plan.width, plan.depth, plan.coupling, 0, plan.depth, B,
+                      _ptr(z), _ptr(objective), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(z_saved_out), _ptr(act_saved), None)
+
+    def __call__(self, stats: Optional[torch.Tensor] = None) -> None:
+        if stats is not None and (stats.dtype != torch.float64 or stats.numel() < STATS_DOUBLES or stats.device != self._dev):
+            raise LsnfError("stats must be a float64 buffer of LSNF_STATS_DOUBLES doubles on the call's device (new_stats())")
+        rc = self._lib.lsnf_forward(*self._head, None if stats is None else stats.data_ptr(), torch.cuda.current_stream(self._dev).cuda_stream)
+        if rc:
+            _lib.check(rc, "lsnf_forward")
+
+
 SMALL_BATCH_AUTO = -2
 
 

@@ -118,6 +118,8 @@ class PipelinedStatsReducer:
             if tuple(b.shape) != (bucket, STATS_DOUBLES) or b.dtype != torch.float64 or not b.is_contiguous():
                 raise ValueError(f"make_buffer(n) must return a contiguous float64 (n, {STATS_DOUBLES}) tensor, got "
                                  f"{tuple(b.shape)} {b.dtype}")
+        # (row views made once: indexing a tensor costs ~2 us of host time, and a strong-scaling step has ~20 us of GPU work)
+        self.rows = [[b[i] for i in range(bucket)] for b in self.banks]
         self.work = [None, None]
         self.pub = [None, None]      # reduced public parts of the banks (multi-rank runs)
         self.sent = [0, 0]           # rows of each bank that travelled in its collective
@@ -132,7 +134,7 @@ class PipelinedStatsReducer:
     def next_buffer(self) -> torch.Tensor:
         if self.fill == 0:                                          # first row of a bank whose collective may be in flight
             self._complete(self.bank)
-        return self.banks[self.bank][self.fill]
+        return self.rows[self.bank][self.fill]
 
     def _complete(self, k: int) -> None:
         """Wait for bank k's collective (a stream-level wait for RCCL) and put the reduced sums back into its rows."""
@@ -165,8 +167,8 @@ class PipelinedStatsReducer:
         self.fill = 0
 
     def submit(self, stats: torch.Tensor) -> None:
-        row = self.banks[self.bank][self.fill]
-        assert stats.data_ptr() == row.data_ptr(), "submit() must receive the buffer handed out by next_buffer()"
+        row = self.rows[self.bank][self.fill]
+        assert stats is row or stats.data_ptr() == row.data_ptr(), "submit() must receive the buffer handed out by next_buffer()"
         self.last = (self.bank, self.fill)
         self.fill += 1
         if self.fill == self.bucket:

@@ -33,6 +33,26 @@ def step():
     s = red.next_buffer(); lsnf_amd.forward(plan, z, out=out, stats=s); red.submit(s)
 print("  bench step (forward + reducer)   %.1f / %.1f" % wall(step))
 red.finish()
+# the same step with several evaluations per collective, over three streams with a reducer each (bench.py's eager timed region)
+for bucket in (1, 4, 8):
+    side = [torch.cuda.Stream() for _ in range(3)]
+    reds = [Multi(dev, bucket=bucket) for _ in side]
+    outs3 = [(torch.empty_like(z), torch.empty(8192, device=dev), torch.empty(8192, device=dev)) for _ in side]
+    cnt = [0]
+    def step3():
+        k = cnt[0] % 3; cnt[0] += 1
+        with torch.cuda.stream(side[k]):
+            s = reds[k].next_buffer(); lsnf_amd.forward(plan, z, out=outs3[k], stats=s); reds[k].submit(s)
+    print("  3 streams, %d evaluation(s) per collective: %.1f / %.1f" % ((bucket,) + wall(step3)))
+    calls = [lsnf_amd.flow.BoundForward(plan, z, o) for o in outs3]
+    def step3b():
+        k = cnt[0] % 3; cnt[0] += 1
+        with torch.cuda.stream(side[k]):
+            s = reds[k].next_buffer(); calls[k](s); reds[k].submit(s)
+    print("     ... with the launch bound once (flow.BoundForward): %.1f / %.1f" % wall(step3b))
+    for r_, s_ in zip(reds, side):
+        with torch.cuda.stream(s_): r_.finish()
+    torch.cuda.synchronize()
 # graph capture of G steps
 try:
     G = 20
