@@ -142,3 +142,34 @@ def test_parameter_gradients_with_a_4_byte_aligned_z_in(lsnf, gpu_device, B):
         grads.append([t.clone() for t in g])
     for a, b in zip(*grads):
         assert (a - b).norm().item() <= 2e-6 * max(a.norm().item(), 1e-6)
+
+
+def test_bound_forward_is_the_same_launch(lsnf, gpu_device):
+    """`flow.BoundForward` (buffers checked and pointers extracted once; bench.py's strong-scaling step): same outputs and in-kernel
+    sums as `forward`, on whatever stream is current; a foreign `stats` buffer is refused."""
+    F = lsnf.flow
+    nz, width, depth, B = 128, 64, 5, 8192
+    p = O.init_params(nz, width, depth, seed=2)
+    plan = lsnf.prepare(lsnf.params_from_state_dict(p, depth, gpu_device), nz, width, depth)
+    z = torch.randn(B, nz, generator=torch.Generator().manual_seed(1)).to(gpu_device)
+    ref_stats = F.new_stats(gpu_device)
+    ref = lsnf.forward(plan, z, stats=ref_stats)
+    out = (torch.empty_like(z), torch.empty(B, device=gpu_device), torch.empty(B, device=gpu_device))
+    fw = F.BoundForward(plan, z, out)
+    for o in out:
+        o.fill_(float("nan"))
+    st = F.new_stats(gpu_device)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fw(st)
+    side.synchronize()
+    assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]) and torch.equal(out[2], ref[2])
+    assert torch.equal(st[4:7], ref_stats[4:7])
+    fw()                                                   # without sums
+    torch.cuda.synchronize()
+    assert torch.equal(out[2], ref[2])
+    with pytest.raises(lsnf.LsnfError):
+        fw(torch.zeros(8, dtype=torch.float64, device=gpu_device))
+    with pytest.raises(lsnf.LsnfError):
+        fw(torch.zeros(F.STATS_DOUBLES, dtype=torch.float32, device=gpu_device))
