@@ -234,7 +234,9 @@ int lsnf_langevin_step(const float* plan, int nz, int width, int depth, int coup
  *                 (fast path: backward from the stash on the bf16 matrix pipe, nothing recomputed; same math mode and
  *                 small-batch threshold in force for both calls; ignored when lsnf_params_fast_path() == 0)
  *   g_z_in      : NULL, or (B, nz) to also receive dL/dz_in (same values as lsnf_backward_z)
- *   workspace   : lsnf_backward_params_workspace_floats() floats, 16-byte aligned.
+ *   workspace   : lsnf_backward_params_workspace_floats() floats, 16-byte aligned.  Opaque between the two calls of the fast path
+ *                 (the forward records there in which form it left h1 / h2: from 12 288 rows the batch contraction runs on the bf16
+ *                 matrix pipe and the large-batch kernels write their arrays tiled); pass the forward's own z_in / z_out / z_saved.
  * Sums over the batch use fp32 atomics when B > 1024 (order, hence last bits, may vary run to run:
  * tests/test_gpu_module.py bounds the spread at B = 65 536 to 2e-6 of each tensor's norm). */
 size_t lsnf_backward_params_workspace_floats(int nz, int width, int depth, int B);
