@@ -38,7 +38,8 @@ hipError_t lsnf_launch_forward3(const LsnfGeo& g, const float* plan, int first_b
                                 int shape16, int fixup, hipStream_t stream, float* hdump = nullptr, int hdump_tiled = 0);
 hipError_t lsnf_launch_forward3q(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                  const float* z_in, const float* objective, float* z_out, float* logdet_out,
-                                 float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4, hipStream_t stream);
+                                 float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4, hipStream_t stream,
+                                 float* hdump = nullptr, int hdump_tiled = 0);
 hipError_t lsnf_launch_forward3p(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                  const float* z_in, const float* objective, float* z_out, float* logdet_out,
                                  float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4, hipStream_t stream);
@@ -303,9 +304,9 @@ int lsnf_forward(const float* plan, int nz, int width, int depth, int coupling, 
                 e = lsnf_launch_forward3(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
                                          z_saved, act_saved, nullptr, vec4, 1, /*fixup=*/1, (hipStream_t)stream, hdump);
         }
-        if (math == LSNF_MATH_BF16X3 && !hdump)        // vector work software-pipelined under 16x16x32 MFMAs (lsnf_fwd3p.hip, lsnf_fwd3q_kernel)
+        if (math == LSNF_MATH_BF16X3 && (!hdump || hdump_tiled))   // vector work software-pipelined under 16x16x32 MFMAs (lsnf_fwd3p.hip, lsnf_fwd3q_kernel)
             e = lsnf_launch_forward3q(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
-                                      z_saved, act_saved, stats, vec4, (hipStream_t)stream);
+                                      z_saved, act_saved, stats, vec4, (hipStream_t)stream, hdump, hdump_tiled);
         if (math == LSNF_MATH_X_BF16X3_PIPE && !hdump) // (research builds) the 32x32x16 kernel with its vector work pipelined under the MFMAs
             e = lsnf_launch_forward3p(g, plan, first_block, n_blocks, B, z_in, objective, z_out, logdet_out, ll_out,
                                       z_saved, act_saved, stats, vec4, (hipStream_t)stream);

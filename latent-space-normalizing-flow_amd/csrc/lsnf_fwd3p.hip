@@ -50,7 +50,8 @@ struct Fwd3pArgs {
     float* z_out; float* logdet_out; float* ll_out;
     int B, nz, half, n_blocks, vec4;
     double* stats;
-    float* z_saved; float* act_saved;  // lsnf_fwd3q_kernel<.., STASH = true>: block outputs 0..n_blocks-2 and the activation stash (lsnf_layout.h LsnfActLayout)
+    float* hdump; int width;           // STASH = 2: h1 / h2 of every block into the parameter-gradient dump, TILED form (lsnf_l16.h l16_store_tiled)
+    float* z_saved; float* act_saved;  // lsnf_fwd3q_kernel<.., STASH >= 1>: block outputs 0..n_blocks-2 and the activation stash (lsnf_layout.h LsnfActLayout)
     unsigned long long* stamps;        // LSNF_STAMPS diagnostic build only: [waves & 2047][64] clock stamps
 };
 
@@ -538,7 +539,7 @@ __device__ __forceinline__ void couple_q16(Tile16& v, const Tile16& t, const Til
 #define LSNF_STASH_PARTS 7    // timing diagnostics (wrong stash): 1 = ReLU masks, 2 = sigma tiles, 4 = block output rows
 #endif
 typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
-struct StashLane { unsigned zoff, soff, moff, msh; };   // per-lane byte offsets: row store, sigma tile, mask words; mask shift 4 * (g >> 1)
+struct StashLane { unsigned zoff, soff, moff, msh, hoff; };   // per-lane byte offsets: row store, sigma tile, mask words; mask shift 4 * (g >> 1)
 // (every store below has soffset = 0: a uniform byte offset -- the second half of a row, the second sigma tile -- is a second descriptor,
 //  base + off / bytes - off, formed on the scalar unit.  With a REGISTER soffset the compiler's hazard recognizer takes a 128-bit
 //  buffer store for safe against an immediately following VALU write of its data registers; on this chip it is not: the first data
@@ -587,6 +588,17 @@ __device__ __forceinline__ void stash_mask_words(const StashRsrc& rs, const Stas
     x = lsnf_pair_or32(x);
     __builtin_amdgcn_raw_buffer_store_b32(x >> 16, rs.r[0], sl.moff + (unsigned)(tile * 64 * 4), 0, 0);
     __builtin_amdgcn_raw_buffer_store_b32(x & 0xffffu, rs.r[0], sl.moff + (unsigned)((tile * 64 + 16) * 4), 0, 0);
+}
+// quad q = 2*ft + st of hidden tile t, through the ReLU, into the tiled h array of the parameter-gradient dump (l16_store_tiled's
+// order: unit ((2t + ft) * 2 + st) * 64 + n * 4 + g of the wave's 32-sample tile; rs.r[t] starts at feature tile t; a padded half
+// of the last feature tile gets the out-of-range offset)
+__device__ __forceinline__ void stash_h_quad(const StashRsrc& rs, const StashLane& sl, int t, int q, const Tile16& h, int width) {
+    const int ft = q >> 1, st = q & 1;
+    f32x4v r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = fmaxf(h.q[q][j], 0.0f);         // (the same v_max as the split's: one instruction serves both)
+    const unsigned off = (32 * t + 16 * ft < width) ? sl.hoff : 0x80000000u;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, r), rs.r[t], off + (unsigned)((ft * 2 + st) * 1024), 0, LSNF_STASH_AUX);
 }
 
 template <int NM, int NV>
@@ -709,19 +721,28 @@ struct QsS4 : QhS4 {
     static constexpr int valu(int i) { return i < 4 ? 34 : ((i >= 6 && i < 9) ? 10 + QhS4::valu(i) : QhS4::valu(i)); }
     static constexpr int stores(int i) { return (i >= 6 && i < 9) ? 2 : ((i >= 9 && i < 13) ? 1 : 0); }
 };
+// STASH = 2 (also the h dump): one more store per quad of h1 / h2, in the step that splits the quad
+struct QxS23 : QsS23 {
+    static constexpr int valu(int i) { return QsS23::valu(i) + (((i >= 4 && i < 12) || i >= 13) ? 2 : 0); }
+    static constexpr int stores(int i) { return QsS23::stores(i) + (((i >= 4 && i < 12) || i >= 13) ? 1 : 0); }
+};
+struct QxS4 : QsS4 {
+    static constexpr int valu(int i) { return QsS4::valu(i) + (i < 4 ? 2 : 0); }
+    static constexpr int stores(int i) { return QsS4::stores(i) + (i < 4 ? 1 : 0); }
+};
 template <class PH> constexpr int stores_after(int last_dma_step) {
     int n = 0;
     for (int i = last_dma_step + 1; i < PH::N; ++i) n += PH::stores(i);
     return n;
 }
 
-template <int WT, int NWAVES, int ST, bool STASH = false>
+template <int WT, int NWAVES, int ST, int STASH = 0>      // STASH: 0 plain, 1 block outputs + activation stash, 2 also the tiled h dump
 __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pArgs a) {
     static_assert(!STASH || ST == 2, "the stash tile is a wave's 32 rows");
-    using TS1a = std::conditional_t<STASH, QsS1a, QhS1a>;
-    using TS1b = std::conditional_t<STASH, QsS1b, QhS1b>;
-    using TS23 = std::conditional_t<STASH, QsS23, QhS23>;
-    using TS4 = std::conditional_t<STASH, QsS4, QhS4>;
+    using TS1a = std::conditional_t<STASH != 0, QsS1a, QhS1a>;
+    using TS1b = std::conditional_t<STASH != 0, QsS1b, QhS1b>;
+    using TS23 = std::conditional_t<STASH == 2, QxS23, std::conditional_t<STASH != 0, QsS23, QhS23>>;
+    using TS4 = std::conditional_t<STASH == 2, QxS4, std::conditional_t<STASH != 0, QsS4, QhS4>>;
     using C = Fwd3pCfg<WT>;
     static_assert(WT == 2, "lsnf_fwd3q_kernel: f_width <= 64 instantiation");
     constexpr int THREADS = 64 * NWAVES;
@@ -761,7 +782,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
     using Left0 = std::integral_constant<int, 0>;
     using LeftS1a = std::integral_constant<int, stores_after<TS1a>(LAST_DMA)>;
     using LeftS1b = std::integral_constant<int, stores_after<TS1b>(LAST_DMA)>;
-    using LeftS23 = std::integral_constant<int, stores_after<TS23>(LAST_DMA)>;
+    using LeftS23 = std::integral_constant<int, stores_after<TS23>(LAST_DMA) + (STASH == 2 ? 1 : 0)>;     // (+ the exposed quad of h2[0] behind S2+S3)
     using LeftS4 = std::integral_constant<int, stores_after<TS4>(LAST_DMA)>;
     const float* dma_src = nullptr; float* dma_dst = nullptr;
     auto dma_arm = [&](int k) {                                          // phase k is about to run: its steps carry phase k+1's pieces
@@ -822,7 +843,10 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
         sl0.soff = tile_byte + ((unsigned)(g >> 1) * 64u + L) * 16u;
         sl0.moff = tile_byte + (unsigned)(al.mask_off * 4) + L * 4u;
         sl0.msh = 4u * (g >> 1);
+        sl0.hoff = (unsigned)(wbase >> 5) * (unsigned)(32 * a.width * 4) + (unsigned)(n * 4 + g) * 16u;
     }
+    const LsnfDumpLayout dl = lsnf_dump_layout(a.B, a.nz, a.width);
+    const unsigned hbytes = (unsigned)(((size_t)a.B + 31) / 32 * 32 * a.width * 4);
     sync_issue(0, Left0{});
     P_STAMP(1, "s_memtime");
 
@@ -849,6 +873,10 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
         //  formed once, ahead of the loop, in thirty registers)
         StashLane sl = sl0;
         if constexpr (STASH) asm volatile("" : "+v"(sl.zoff), "+v"(sl.soff), "+v"(sl.moff));
+        if constexpr (STASH == 2) asm volatile("" : "+v"(sl.hoff));
+        const float* hd = (STASH == 2) ? a.hdump + (size_t)blk * dl.per_block : a.z_out;
+        const StashRsrc rs_h1 = stash_rsrc(STASH == 2 ? hd + dl.off_h1 : hd, STASH == 2 ? hbytes : 0u, 4096u);
+        const StashRsrc rs_h2 = stash_rsrc(STASH == 2 ? hd + dl.off_h2 : hd, STASH == 2 ? hbytes : 0u, 4096u);
         unsigned mk1[2][2], mk2[2][2], mk3[2][2];   // ReLU bits of h1[1], h2[0], h2[1] until their words are stored (early in S4: see sync_issue)
 
         if (blk == 1) P_STAMP(10, "s_memtime");
@@ -918,6 +946,11 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
                     if constexpr (i >= 8 && i < 12) mask_q16(hh[1], i - 8, mk1);
                     if constexpr (i >= 13) mask_q16(hh[2], i - 13, mk2);
                 }
+                if constexpr (STASH == 2) {
+                    if constexpr (i >= 4 && i < 8) stash_h_quad(rs_h1, sl, 0, i - 4, hh[0], a.width);
+                    if constexpr (i >= 8 && i < 12) stash_h_quad(rs_h1, sl, 1, i - 8, hh[1], a.width);
+                    if constexpr (i >= 13) stash_h_quad(rs_h2, sl, 0, i - 13, hh[2], a.width);
+                }
             }, dma_step);
         }
         if (blk == 1) P_STAMP(13, "s_memtime");
@@ -929,6 +962,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
             const float* bv = bias_lane_ptr(cb, g);
             split_q16<true, ST>(hh[2], 3, h2s[0]);       // (the last quad of h2[0]: exposed, S4's first step needs it)
             if constexpr (STASH) mask_q16(hh[2], 3, mk2);
+            if constexpr (STASH == 2) stash_h_quad(rs_h2, sl, 0, 3, hh[2], a.width);
             sync_issue(k0 + 3, LeftS23{});
             dma_arm(k0 + 3);
             run_phase16<TS4, ST>(tp, bv, h2s, buf0 + ((k0 + 3) & 1) * SLOT, lane, [&](auto ic) {
@@ -940,6 +974,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
                     if constexpr (i == 7) stash_mask_words(rs_ac, sl, WT + 0, mk2);
                     if constexpr (i == 8) stash_mask_words(rs_ac, sl, WT + 1, mk3);
                 }
+                if constexpr (STASH == 2 && i < 4) stash_h_quad(rs_h2, sl, 1, i, hh[3], a.width);
                 // k-tile 1: p0's halves are complete after steps 8, 9; t0's after 10, 11; p1's after 12, 13; t1's after 14, 15
                 if constexpr (i >= 9 && i < 13) { sigmoid_q16<ST>(tp[0], i - 9, lsum); if constexpr (STASH) stash_sigma_quad(rs_ac, sl, 0, i - 9, tp[0]); }
                 if constexpr (i == 12) couple_q16<ST>(v[2], tp[1], tp[0], 0);
@@ -1010,7 +1045,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
     P_STAMP(51, "s_memrealtime");
 }
 
-template <int WT, int NWAVES, int ST, bool STASH = false>
+template <int WT, int NWAVES, int ST, int STASH = 0>
 hipError_t launch_fwd3q_w(const Fwd3pArgs& a, hipStream_t stream) {
     using C = Fwd3pCfg<WT>;
     const size_t lds = ((size_t)a.n_blocks * C::CONST_FLOATS + 2 * (size_t)C::SLOT3) * sizeof(float);
@@ -1067,8 +1102,11 @@ hipError_t lsnf_launch_forward3p(const LsnfGeo& g, const float* plan, int first_
 // f_width <= 64, no stash / parameter-gradient dump); hipErrorInvalidValue = not covered, the caller falls back to lsnf_fwd3.hip
 hipError_t lsnf_launch_forward3q(const LsnfGeo& g, const float* plan, int first_block, int n_blocks, int B,
                                  const float* z_in, const float* objective, float* z_out, float* logdet_out,
-                                 float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4, hipStream_t stream) {
+                                 float* ll_out, float* z_saved, float* act_saved, double* stats, int vec4, hipStream_t stream,
+                                 float* hdump, int hdump_tiled) {
     if (g.HT != 2 || g.WT != 2) return hipErrorInvalidValue;
+    // the h dump of the parameter gradients: in its tiled form only, with both parts of the stash, for the whole stack
+    if (hdump && (!hdump_tiled || !act_saved || (n_blocks > 1 && !z_saved) || first_block != 0 || (g.width & 15))) return hipErrorInvalidValue;
     // with the stash, or a part of it (STASH instantiation: buffer stores of whole 16-byte groups through 32-bit offsets): rows that take
     // 16-byte accesses, and a block of rows / of stash tiles below 2 GiB
     const bool stash = act_saved != nullptr || z_saved != nullptr;
@@ -1081,6 +1119,7 @@ hipError_t lsnf_launch_forward3q(const LsnfGeo& g, const float* plan, int first_
     a.z_in = z_in; a.objective = objective; a.z_out = z_out; a.logdet_out = logdet_out; a.ll_out = ll_out;
     a.B = B; a.nz = g.nz; a.half = g.half; a.n_blocks = n_blocks; a.vec4 = vec4; a.stats = stats;
     a.z_saved = z_saved; a.act_saved = act_saved ? act_saved + (size_t)first_block * lsnf_act_layout(B, g.HT, g.WT).per_block : nullptr;
+    a.hdump = hdump; a.width = g.width;
     a.stamps = nullptr;
 #ifdef LSNF_STAMPS
     { extern unsigned long long* g_lsnf_stamps;
@@ -1091,7 +1130,8 @@ hipError_t lsnf_launch_forward3q(const LsnfGeo& g, const float* plan, int first_
     // per wave so that the grid still covers the chip -- 8 waves x 16 rows down to 16 384 rows, 4 waves x 16 rows below
     static const char* shape = getenv("LSNF_FWD3Q_SHAPE");     // experiment knob (tools/shard_times.py): "82", "42", "81", "41"
     const int sh = shape ? atoi(shape) : (B > 128 * 256 ? 82 : (B > 64 * 256 ? 81 : 41));
-    if (stash) return (sh == 82) ? launch_fwd3q_w<2, 8, 2, true>(a, stream) : launch_fwd3q_w<2, 4, 2, true>(a, stream);
+    if (hdump) return (sh == 82) ? launch_fwd3q_w<2, 8, 2, 2>(a, stream) : launch_fwd3q_w<2, 4, 2, 2>(a, stream);
+    if (stash) return (sh == 82) ? launch_fwd3q_w<2, 8, 2, 1>(a, stream) : launch_fwd3q_w<2, 4, 2, 1>(a, stream);
     if (sh == 82) return launch_fwd3q_w<2, 8, 2>(a, stream);
     if (sh == 42) return launch_fwd3q_w<2, 4, 2>(a, stream);
     if (sh == 81) return launch_fwd3q_w<2, 8, 1>(a, stream);

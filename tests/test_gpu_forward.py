@@ -414,6 +414,20 @@ def test_pipelined_forward_writes_the_phase_separated_stash(lsnf, gpu_device, nz
                 assert torch.equal(got[3], ref[3])
             if want_act:
                 assert torch.equal(got[4].view(torch.int32), ref[4].view(torch.int32))
+        # with the parameter-gradient h dump (STASH = 2 instantiation; tiled form from 12 288 rows): the whole workspace, bit for bit
+        if B >= 12288 and depth > 1:
+            def run_ws(mode):
+                F.set_math_mode(mode)
+                act = F.new_act_saved(plan, B, gpu_device); act.fill_(float("nan"))
+                ws = F.new_params_workspace(plan, B, gpu_device); ws.fill_(float("nan"))
+                saved = torch.full((depth - 1, B, nz), float("nan"), device=gpu_device)
+                out = lsnf.forward(plan, z, act_saved=act, z_saved_out=saved, params_ws=ws)
+                torch.cuda.synchronize()
+                return out[0], saved, act, ws
+            a, b = run_ws(F.MATH_BF16X3_PHASED), run_ws(F.MATH_BF16X3)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+            assert torch.equal(a[2].view(torch.int32), b[2].view(torch.int32))
+            assert torch.equal(a[3].view(torch.int32), b[3].view(torch.int32))
     finally:
         F.set_small_batch_max(prev_small)
         F.set_math_mode(prev_math)
