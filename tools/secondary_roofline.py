@@ -33,13 +33,13 @@ def trace(key, B):
 TABLE = {
     "reverse": ({100: "lsnf_small3_rev_kernel", 65536: "lsnf_rev3_kernel"}, F, 8 * NZ + 8, "bf16"),
     # the stash-writing instantiation of the pipelined forward (template flag true): + block outputs + stash
-    "forward + stash (pipelined)": ({100: "lsnf_small3_fwd_kernel", 65536: "lsnf_fwd3q_kernel&true>"}, F, 8 * NZ + 8 + (D - 1) * 4 * NZ + D * STASH, "bf16"),
+    "forward + stash (pipelined)": ({100: "lsnf_small3_fwd_kernel", 65536: "lsnf_fwd3q_kernel<2, 8, 2, 1>"}, F, 8 * NZ + 8 + (D - 1) * 4 * NZ + D * STASH, "bf16"),
     # (kernel names carry the template flags: "false>" = no parameter-gradient dump; the Langevin update runs the same kernel)
     "backward_z_from_stash (+ Langevin update)": ({100: "lsnf_small3_bwd_kernel&false>", 65536: "lsnf_bwd3_kernel&false>"}, F, 4 * NZ * 2 + D * (2 * NZ + STASH), "bf16"),
     # (65 536 rows: tiled dump, g_v as its first half only)
     "backward_from_stash + g dump": ({100: "lsnf_small3_bwd_kernel&true>", 65536: "lsnf_bwd3_kernel&true>"}, F, 4 * NZ * 2 + D * (2 * NZ + STASH) + D * 4 * (NZ // 2 + 2 * W + 2 * (NZ // 2)), "bf16"),
     # (one kernel serves forward / + stash / + h dump: the median is over the driver's mix of the three)
-    "forward + stash + h dump (65 536 rows: the phase-separated kernel; 100 rows: the latency kernel's mix of the three forms)": ({100: "lsnf_small3_fwd_kernel", 65536: "lsnf_fwd3b_kernel"}, F, 8 * NZ + 8 + (D - 1) * 4 * NZ + D * STASH + D * 8 * W, "bf16"),
+    "forward + stash + h dump (65 536 rows: the pipelined kernel, tiled h dump; 100 rows: the latency kernel's mix of the three forms)": ({100: "lsnf_small3_fwd_kernel", 65536: "lsnf_fwd3q_kernel<2, 8, 2, 2>"}, F, 8 * NZ + 8 + (D - 1) * 4 * NZ + D * STASH + D * 8 * W, "bf16"),
     "restash": ({100: "lsnf_small3_restash_kernel", 65536: "lsnf_small3_restash_kernel"}, D * 2 * (NZ // 2 * W + W * W + W * NZ // 2), D * (2 * NZ + STASH), "bf16"),
     # (65 536 rows: lsnf_params3.hip on the bf16 pipe, h2 read once; 100 rows: the fp32-MFMA kernel, h2 read per task)
     "batch_contraction": ({100: "lsnf_tn_gemm_kernel", 65536: "lsnf_contract_x3_kernel"}, F, D * 4 * (2 * NZ + NZ // 2 + 4 * W + 2 * (NZ // 2) + NZ // 2), "bf16 (65536) / fp32 (100)"),
