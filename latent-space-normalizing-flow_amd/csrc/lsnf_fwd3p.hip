@@ -771,6 +771,9 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lsnf_fwd3q_kernel(const Fwd3pA
     // the free buffer -- no DMA under a branch; the epilogue waits for it before LDS is reused or released.
     // (STASH: `left` = the stash stores of the phase just run that may stay in flight, see stores_after())
     auto sync_issue = [&](int k, auto left) {
+#ifdef LSNF_ABL_SKIPSYNC       // timing diagnostic (racy, wrong numbers): phase boundaries (k & 3) in the mask are not synchronised at all
+        if ((LSNF_ABL_SKIPSYNC >> (k & 3)) & 1) return;
+#endif
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(decltype(left)::value) : "memory");
         __syncthreads();
 #ifdef LSNF_FWD3Q_BURST_DMA
