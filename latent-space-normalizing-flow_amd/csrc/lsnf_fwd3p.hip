@@ -1109,7 +1109,8 @@ hipError_t lsnf_launch_forward3q(const LsnfGeo& g, const float* plan, int first_
                                  float* hdump, int hdump_tiled) {
     if (g.HT != 2 || g.WT != 2) return hipErrorInvalidValue;
     // the h dump of the parameter gradients: in its tiled form only, with both parts of the stash, for the whole stack
-    if (hdump && (!hdump_tiled || !act_saved || (n_blocks > 1 && !z_saved) || first_block != 0 || (g.width & 15))) return hipErrorInvalidValue;
+    if (hdump && (!hdump_tiled || !act_saved || (n_blocks > 1 && !z_saved) || first_block != 0 || (g.width & 15) ||
+                  ((size_t)B + 32) * g.width * 4 >= (1ull << 31))) return hipErrorInvalidValue;
     // with the stash, or a part of it (STASH instantiation: buffer stores of whole 16-byte groups through 32-bit offsets): rows that take
     // 16-byte accesses, and a block of rows / of stash tiles below 2 GiB
     const bool stash = act_saved != nullptr || z_saved != nullptr;
