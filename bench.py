@@ -339,10 +339,16 @@ def main():
             # sums is submitted asynchronously on RCCL's stream and overlaps the following kernels (banks alternate)
             k = counter[0] % len(streams)
             counter[0] += 1
-            with torch.cuda.stream(streams[k]):
-                stats = reducers[k].next_buffer()
-                calls[k](stats)                     # == lsnf_amd.forward(plan, z, out=outs[k], stats=stats)
-                reducers[k].submit(stats)
+            red = reducers[k]
+            if red.touches_stream():                # first / last evaluation of a bank: the reducer waits for / issues a collective
+                with torch.cuda.stream(streams[k]):
+                    stats = red.next_buffer()
+                    calls[k](stats)                 # == lsnf_amd.forward(plan, z, out=outs[k], stats=stats)
+                    red.submit(stats)
+            else:                                   # in between: the launch names its stream, nothing else touches one
+                stats = red.next_buffer()
+                calls[k](stats, streams[k])
+                red.submit(stats)
 
         # Clock ramp: MI355X needs ~50 ms of sustained load before it holds its steady shader clock (2.07 GHz in the first
         # ~100 launches, 2.39 GHz afterwards).  The metric is steady-state throughput, so the chip is brought there right

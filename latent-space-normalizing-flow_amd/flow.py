@@ -207,10 +207,12 @@ class BoundForward:
         self._head = (_ptr(plan.buf), plan.nz, plan.width, plan.depth, plan.coupling, 0, plan.depth, B,
                       _ptr(z), _ptr(objective), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(z_saved_out), _ptr(act_saved), None)
 
-    def __call__(self, stats: Optional[torch.Tensor] = None) -> None:
+    def __call__(self, stats: Optional[torch.Tensor] = None, stream: Optional[torch.cuda.Stream] = None) -> None:
+        """stream: the stream to launch on (default: the current one) -- passing it saves the `with torch.cuda.stream(...)` around the call."""
         if stats is not None and (stats.dtype != torch.float64 or stats.numel() < STATS_DOUBLES or stats.device != self._dev):
             raise LsnfError("stats must be a float64 buffer of LSNF_STATS_DOUBLES doubles on the call's device (new_stats())")
-        rc = self._lib.lsnf_forward(*self._head, None if stats is None else stats.data_ptr(), torch.cuda.current_stream(self._dev).cuda_stream)
+        sp = (torch.cuda.current_stream(self._dev) if stream is None else stream).cuda_stream
+        rc = self._lib.lsnf_forward(*self._head, None if stats is None else stats.data_ptr(), sp)
         if rc:
             _lib.check(rc, "lsnf_forward")
 

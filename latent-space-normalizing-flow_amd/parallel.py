@@ -131,6 +131,12 @@ class PipelinedStatsReducer:
     def _multi(self):
         return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
 
+    def touches_stream(self) -> bool:
+        """Will the next next_buffer() / submit() pair wait for or issue a collective (i.e. must it run with the evaluation's stream
+        current)?  Only at the first and the last row of a bank: in between, a caller that launches on an explicit stream
+        (`flow.BoundForward(stats, stream)`) can skip the `with torch.cuda.stream(...)` around the step."""
+        return self.fill == 0 or self.fill == self.bucket - 1
+
     def next_buffer(self) -> torch.Tensor:
         if self.fill == 0:                                          # first row of a bank whose collective may be in flight
             self._complete(self.bank)

@@ -50,6 +50,15 @@ for bucket in (1, 4, 8):
         with torch.cuda.stream(side[k]):
             s = reds[k].next_buffer(); calls[k](s); reds[k].submit(s)
     print("     ... with the launch bound once (flow.BoundForward): %.1f / %.1f" % wall(step3b))
+    def step3c():
+        k = cnt[0] % 3; cnt[0] += 1
+        r = reds[k]
+        if r.touches_stream():
+            with torch.cuda.stream(side[k]):
+                s = r.next_buffer(); calls[k](s); r.submit(s)
+        else:
+            s = r.next_buffer(); calls[k](s, side[k]); r.submit(s)
+    print("     ... and the stream named in the call between a bank's ends: %.1f / %.1f" % wall(step3c))
     for r_, s_ in zip(reds, side):
         with torch.cuda.stream(s_): r_.finish()
     torch.cuda.synchronize()
