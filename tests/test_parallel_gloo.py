@@ -150,3 +150,21 @@ def test_two_rank_gloo_matches_full_batch():
     assert r0["n"] == sum(v.numel() for v in ref.values())
     for k, v in ref.items():
         assert (torch.from_numpy(r0["grads"][k]) - v).norm().item() <= 1e-5 * max(v.norm().item(), 1e-3), k
+
+
+def test_reducer_says_when_it_touches_a_stream():
+    """`touches_stream()`: only the first evaluation of a bank (the reducer may wait for the bank's previous collective) and the
+    last one (it issues the collective) need the evaluation's stream to be current; bench.py names the stream in the launch itself
+    for the ones in between."""
+    import torch
+    from lsnf_amd import parallel as P
+    red = P.PipelinedStatsReducer(torch.device("cpu"), bucket=4,
+                                  make_buffer=lambda n: torch.zeros(n, P.STATS_DOUBLES, dtype=torch.float64))
+    seen = []
+    for _ in range(9):
+        seen.append(red.touches_stream())
+        s = red.next_buffer()
+        red.submit(s)
+    assert seen == [True, False, False, True, True, False, False, True, True]
+    one = P.PipelinedStatsReducer(torch.device("cpu"), bucket=1, make_buffer=lambda n: torch.zeros(n, P.STATS_DOUBLES, dtype=torch.float64))
+    assert one.touches_stream()
