@@ -88,6 +88,13 @@ def main():
 
     it = [0]
     sampler = None
+    if world > 1 and args.backend == "gloo" and not args.no_graph:
+        # ranks that SHARE one card (the gloo rehearsal): back-to-back graph launches of two processes on one device take seconds per
+        # iteration in this ROCm build (3.9-7.9 s vs 33.8 ms eager) -- the rehearsal runs the eager loop
+        if rank == 0:
+            print("[train_synthetic] gloo backend = ranks share a GPU: eager Langevin loop (graph replay from several processes on one "
+                  "device is pathologically slow here)", file=sys.stderr)
+        args.no_graph = True
     if not args.no_graph:       # one Langevin step (generator gradient + fused flow update) captured once, replayed K times
         sampler = langevin.GraphedLangevinSampler(netG.module if world > 1 else netG, netF, B, nz, x.shape,
                                                   g_l_step_size=step_size, g_llhd_sigma=sigma, seed=1234, row0=rank * B)
