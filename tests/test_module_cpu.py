@@ -101,6 +101,11 @@ def test_geometry_queries_need_no_gpu():
     assert lib.lsnf_plan_floats(128, 64, 17, 1) == 0
     assert lib.lsnf_plan_floats(128, 64, 5, 0) == lib.lsnf_plan_floats(128, 64, 5, 1) and lib.lsnf_plan_floats(128, 64, 5, 2) == 0
     assert lib.lsnf_backward_params_workspace_floats(128, 64, 5, 100) > 0
+    # the per-sample arrays of the parameter-gradient workspace are sized in whole 32-sample tiles (the large-batch kernels write whole
+    # tiles): every batch size of a tile needs the same workspace, and a tile more needs 32 rows x 7 arrays x 5 blocks more
+    ws = lambda B: lib.lsnf_backward_params_workspace_floats(128, 64, 5, B)
+    assert ws(97) == ws(100) == ws(128) and ws(129) > ws(128)
+    assert ws(160) - ws(128) == 5 * 32 * (128 + 64 + 64 + 64 + 64 + 64 + 64)
 
 
 def test_pick_device_without_gpu_is_loud(monkeypatch):
