@@ -25,7 +25,7 @@ clock ramp and ONE warm-up; `ms_per_step` is the MEDIAN of the R repetitions, `m
 for the single-stream figure); the kernel-only loop of the roofline is timed per launch with HIP events and reports its median.
 
 `--shard-of N` (one GPU): what ONE GPU of an N-GPU strong-scaling job does per step -- rows = 65 536 / N, same stream
-rotation, in-kernel sums, the bucket-1 reducer -- next to the full-size step of the same run; prints the per-shard ms/step and
+rotation, in-kernel sums, the same reducer protocol -- next to the full-size step of the same run; prints the per-shard ms/step and
 the N-GPU ceiling it implies (65 536 rows / shard time: no communication, no straggler), i.e. the bound on strong scaling that
 one GPU decides.
 
@@ -196,7 +196,8 @@ def shard_mode(args, world, rank, dev, z_full, make_run, timed, summarize, ramp_
         return 2
     rows = B_GLOBAL // n
     z = z_full[:rows].contiguous()
-    runs = {"shard": (make_run(z, 1, streams), make_run(z, 1, [main_stream])),
+    bk = max(1, args.strong_bucket)            # the reducer protocol of the N-GPU run this stands for (no collective on one GPU)
+    runs = {"shard": (make_run(z, bk, streams), make_run(z, bk, [main_stream])),
             "full": (make_run(z_full, 1, streams), make_run(z_full, 1, [main_stream]))}
     ramp_out(rows), ramp_out(B_GLOBAL)
     torch.cuda.synchronize()
@@ -225,7 +226,7 @@ def shard_mode(args, world, rank, dev, z_full, make_run, timed, summarize, ramp_
         "untimed_launches_before_timed_region": max(0, args.ramp) + args.warmup,
         "config": {"workload": f"CIFAR-10 flow prior nz=128 f_width=64 f_depth=5 affine, forward+logdet+log-prob with in-kernel "
                                f"sums, {rows} of the 65536 synthetic rows of one evaluation (the shard of GPU 0 of {n}); "
-                               f"bucket-1 reducer, no collective (one GPU)",
+                               f"reducer with {bk} evaluation(s) per bank as in the N-GPU run, no collective (one GPU)",
                    "streams": len(streams), "clock_ramp_launches_before_warmup": max(0, args.ramp)},
     }
     print(json.dumps(line), flush=True)
